@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — UAV-steps/sec of the fused UavSystem::makeStep() kernel on N MI355X (one process per GPU).
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through torch.distributed.run.
+A "step" is one makeStep(dt = 1 ms) of every UAV of the rank's shard (one kernel launch over the whole batch, state
+resident in HBM).  Workload at every N: BASELINE.json configs[2] — 100 000 x500 UAVs per GPU, actuator-level references,
+no collisions (weak scaling: UAVs are independent, no data-path collective).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+DT = 0.001
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+# algorithmic bytes per UAV-step: one read + one write of everything the step must touch, FP64
+BYTES_PER_UAV_STEP = {
+    "actuator": (25 + 3 + 4 + 1) * 8 + 4 + (25 + 3) * 8,            # 492 B  (n_motors = 4)
+    "position": (25 + 3 + 1 + 24 + 4) * 8 + 4 + (25 + 3 + 24) * 8,  # 876 B
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--uavs", type=int, default=100_000, help="UAVs per GPU")
+    ap.add_argument("--workload", choices=["actuator", "position", "position+collisions"], default="actuator")
+    ap.add_argument("--arith", choices=["literal", "fast"], default="literal")
+    ap.add_argument("--substeps", type=int, default=1, help="makeStep rounds fused per launch (state kept in registers)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(n, workload, seed):
+    import helpers
+    rng = np.random.default_rng(seed)
+    if workload == "actuator":
+        st = helpers.random_state(rng, n, 4)
+        cmd = rng.uniform(0.35, 0.60, (n, 4))
+    else:
+        side = (64.0 * n) ** (1.0 / 3.0)  # 64 m^3 per UAV (BASELINE config 4), cube-shaped box
+        st = helpers.random_state(rng, n, 4, tilted=True)
+        st["x"] = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
+        cmd = np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
+    return st, cmd
+
+
+def cpu_baseline(args, st, cmd):
+    """The oracle (scalar C restatement of the reference, 1 thread like the reference's serial loop) timed on a bounded
+    sample of the same workload."""
+    import helpers
+    from oracle import oracle_swarm as O
+    n = min(args.uavs, 20_000)
+    o = O.OracleSwarm(n)
+    po = helpers.oracle_params("x500", ground_enabled=True)
+    o.construct(0, n, po)
+    for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+        getattr(o, nm)(0, n)
+    o.set_state(0, n, st["x"][:n], st["v"][:n], st["R"][:n], st["omega"][:n], st["motor_rpm"][:n])
+    o.set_input(0, n, O.ACTUATOR_CMD if args.workload == "actuator" else O.POSITION_CMD, cmd[:n])
+    coll = args.workload.endswith("collisions")
+    o.step_n(DT, 2)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        if coll:
+            o.step(DT)
+            o.handle_collisions(True, False, 100.0)
+            steps += 1
+        else:
+            o.step_n(DT, 5)
+            steps += 5
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds:
+            break
+    return {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c -O2 -ffp-contract=off, 1 thread"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import mrs_multirotor_simulator_amd as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    n = args.uavs
+    st, cmd = make_inputs(n, args.workload, seed=3 + rank)
+    sw = M.Swarm(n, device=local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
+    sw.construct(0, n, M.model_params("x500", ground_enabled=True))
+    sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    sw.set_input(0, n, M.ACTUATOR_CMD if args.workload == "actuator" else M.POSITION_CMD, cmd)
+    coll = args.workload.endswith("collisions")
+
+    def run(k):
+        if coll:
+            sw.tick_n(DT, k, True, False, 100.0)
+        else:
+            sw.step_n(DT, k, args.substeps)
+
+    def barrier():
+        sw.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sw.synchronize()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # second pass of the same K steps with a hipEvent pair around every step-kernel launch on the swarm's stream
+    sw.set_profiling(True)
+    run(args.steps)
+    sw.synchronize()
+    kern_ms, n_launch = sw.last_step_kernel_ms()
+    sw.set_profiling(False)
+
+    assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
+    if rank == 0:
+        key = "actuator" if args.workload == "actuator" else "position"
+        per_launch_steps = args.substeps if not coll else 1
+        alg_bytes = BYTES_PER_UAV_STEP[key] * n * per_launch_steps
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {args.workload} references, dt=1 ms, RK4, ground on"
+                       if args.workload == "actuator" else f"{n} x500 UAVs per GPU, {args.workload}, dt=1 ms",
+                       "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
+                       "parallelism": f"{world} independent shard(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": f"mrs_uav_step_{args.arith}", "kernel_avg_ms": kern_ms, "launches": n_launch,
+                         "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
+                         "method": "hipEvent pair around each launch on the swarm's stream, second pass of the same K steps"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, st, cmd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+/*
+ * mrs_swarm.h — C ABI of the MI355X-native multi-UAV stepper (libmrs_swarm.so).
+ *
+ * Drop-in boundary for the reference's UavSystem::makeStep() hot path: a whole swarm of
+ * mrs_multirotor_simulator::UavSystem objects lives on one GPU as SoA FP64 state; every entry point
+ * below replaces the per-UAV C++ call named next to it (paths relative to /root/reference).
+ * Plain C types, caller-owned host buffers, int return codes (MRS_OK == 0) — the reference itself
+ * signals no errors on this path.  The header-only C++ facade
+ * include/mrs_multirotor_simulator/uav_system/uav_system.hpp re-exports the reference's class
+ * names on top of this ABI.
+ *
+ * There is NO CPU fallback: every compute entry point fails with MRS_ERR_HIP when no gfx950 device
+ * is usable.
+ */
+#ifndef MRS_SWARM_H
+#define MRS_SWARM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRS_MAX_MOTORS 8
+
+enum { MRS_OK = 0, MRS_ERR_ARG = 1, MRS_ERR_HIP = 2, MRS_ERR_RANGE = 3, MRS_ERR_TYPES = 4 };
+
+/* UavSystem::INPUT_MODE — include/mrs_multirotor_simulator/uav_system/uav_system.hpp:19-32 */
+enum {
+  MRS_INPUT_UNKNOWN = 0,
+  MRS_ACTUATOR_CMD,
+  MRS_CONTROL_GROUP_CMD,
+  MRS_ATTITUDE_RATE_CMD,
+  MRS_ATTITUDE_CMD,
+  MRS_TILT_HDG_RATE_CMD,
+  MRS_ACCELERATION_HDG_RATE_CMD,
+  MRS_ACCELERATION_HDG_CMD,
+  MRS_VELOCITY_HDG_RATE_CMD,
+  MRS_VELOCITY_HDG_CMD,
+  MRS_POSITION_CMD
+};
+
+/* the four std::optional feed-forward slots — uav_system.hpp:112-115 */
+enum { MRS_FF_VELOCITY_HDG_RATE = 0, MRS_FF_VELOCITY_HDG, MRS_FF_ACCELERATION_HDG_RATE, MRS_FF_ACCELERATION_HDG };
+
+/* arithmetic flavour of the step kernel */
+enum {
+  MRS_ARITH_LITERAL = 0, /* reference operation order, no FMA contraction: bit-comparable with a scalar CPU restatement */
+  MRS_ARITH_FAST    = 1  /* FMA contraction + reciprocal/triangular simplifications; same results to ~1e-12 relative */
+};
+
+/* MultirotorModel::ModelParams — uav_system/multirotor_model.hpp:24-88 (matrices row-major) */
+typedef struct {
+  int32_t n_motors;
+  int32_t ground_enabled;
+  int32_t takeoff_patch_enabled;
+  int32_t _pad;
+  double  g, mass, kf, km, prop_radius, arm_length, body_height, motor_time_constant;
+  double  max_rpm, min_rpm, air_resistance_coeff, ground_z;
+  double  J[9];
+  double  allocation_matrix[4 * MRS_MAX_MOTORS]; /* row r, motor m at [r*MRS_MAX_MOTORS + m] */
+} mrs_model_params_t;
+
+typedef struct { int32_t desaturation; int32_t _pad; } mrs_mixer_params_t;                       /* controllers/mixer.hpp:14-17 */
+typedef struct { double kp, kd, ki; } mrs_rate_params_t;                                        /* controllers/rate_controller.hpp:14-19 */
+typedef struct { double kp, kd, ki, max_rate_roll_pitch, max_rate_yaw; } mrs_attitude_params_t; /* controllers/attitude_controller.hpp:14-21 */
+typedef struct { double kp, kd, ki, max_acceleration; } mrs_velocity_params_t;                  /* controllers/velocity_controller.hpp:14-20 */
+typedef struct { double kp, kd, ki, max_velocity; } mrs_position_params_t;                      /* controllers/position_controller.hpp:14-20 */
+
+/* per-swarm event counters replacing the std::cout warnings of controllers/attitude_controller.hpp:196,236,245
+ * and counting the NaN rollbacks of multirotor_model.hpp:228-233 */
+typedef struct {
+  uint64_t hdg_rate_denom_small;
+  uint64_t projected_norm_small;
+  uint64_t yaw_rate_not_finite;
+  uint64_t nan_rollback;
+} mrs_diag_t;
+
+typedef struct mrs_swarm mrs_swarm_t;
+
+/* ---- parameter helpers (host only) ---- */
+/* ModelParams::ModelParams() x500 defaults — multirotor_model.hpp:26-66 (ground_z := 0; uninitialised there) */
+int mrs_model_params_default(mrs_model_params_t* p);
+/* UavSystemRos::calculateInertia — src/uav_system_ros.cpp:664-671 */
+int mrs_calculate_inertia(mrs_model_params_t* p);
+/* allocation-matrix row scaling applied to the YAML matrix — src/uav_system_ros.cpp:100-103 */
+int mrs_scale_allocation(mrs_model_params_t* p);
+
+/* ---- lifetime ---- */
+/* std::vector<std::unique_ptr<UavSystemRos>> uavs_ — src/multirotor_simulator.cpp:70,150-157.
+ * All UAVs start as UavSystem() (default ctor). device_id < 0 -> current device. */
+int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out);
+int mrs_swarm_destroy(mrs_swarm_t* s);
+int mrs_swarm_size(const mrs_swarm_t* s, int32_t* n_uavs);
+int mrs_swarm_set_arith(mrs_swarm_t* s, int32_t arith);
+/* the HIP stream every launch of this swarm goes to (hipStream_t as void*) */
+int mrs_swarm_stream(const mrs_swarm_t* s, void** stream);
+int mrs_swarm_synchronize(mrs_swarm_t* s);
+const char* mrs_last_error(void);
+
+/* ---- construction / parameters ---- */
+/* UavSystem ctors — uav_system.hpp:127-153.  params==NULL: UavSystem(void); pos==NULL: UavSystem(params)
+ * (no setStatePos); else UavSystem(params, spawn_pos, spawn_heading).  pos: count x 3, heading: count. */
+int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params,
+                        const double* pos, const double* heading);
+/* UavSystem::setParams — uav_system.hpp:404-409 (re-creates all controllers with DEFAULT gains, fresh PIDs) */
+int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params);
+/* UavSystem::getParams — uav_system.hpp:395 (takeoff_patch_enabled reflects the flag the step may have cleared) */
+int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out);
+/* UavSystem::set{Mixer,RateController,AttitudeController,VelocityController,PositionController}Params —
+ * uav_system.hpp:433-451; each resets the PIDs of that controller */
+int mrs_swarm_set_mixer_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_mixer_params_t* p);
+int mrs_swarm_set_rate_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_rate_params_t* p);
+int mrs_swarm_set_attitude_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_attitude_params_t* p);
+int mrs_swarm_set_velocity_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_velocity_params_t* p);
+int mrs_swarm_set_position_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_position_params_t* p);
+/* UavSystem::getMixerAllocation — uav_system.hpp:415 (n_motors x 4, row-major) */
+int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out);
+
+/* ---- commands ---- */
+/* UavSystem::setInput(...) x11 — uav_system.hpp:175-248.  payload: count x stride doubles per UAV:
+ *   ACTUATOR: motors[n_motors] | CONTROL_GROUP: roll,pitch,yaw,throttle | ATTITUDE_RATE: rx,ry,rz,throttle
+ *   ATTITUDE: R[9] row-major, throttle | TILT_HDG_RATE: tilt[3], heading_rate, throttle
+ *   ACCELERATION_HDG(_RATE) / VELOCITY_HDG(_RATE) / POSITION: vec[3], heading(_rate) | INPUT_UNKNOWN: none */
+int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride);
+/* UavSystem::setFeedforward(...) x4 — uav_system.hpp:254-272.  payload: vec[3], heading(_rate) */
+int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride);
+/* UavSystem::applyForce — uav_system.hpp:295; force: count x 3 */
+int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const double* force);
+/* UavSystem::crash / hasCrashed — uav_system.hpp:278,286 */
+int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count);
+int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out);
+
+/* ---- the hot path ---- */
+/* for (i) uavs_[i]->makeStep(dt) — src/multirotor_simulator.cpp:211-213 -> UavSystem::makeStep, uav_system.hpp:304-380.
+ * Asynchronous on the swarm's stream. */
+int mrs_swarm_step(mrs_swarm_t* s, double dt);
+/* n_steps consecutive makeStep(dt) rounds; substeps_per_launch > 1 keeps the state in registers across that many
+ * steps inside one launch (legal while commands are constant and collisions are off; results identical). */
+int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substeps_per_launch);
+/* MultirotorSimulator::handleCollisions — src/multirotor_simulator.cpp:295-359 (kd-tree replaced by a spatial hash) */
+int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, double rebounce);
+/* n_ticks of the timerMain order: makeStep for all, then handleCollisions — src/multirotor_simulator.cpp:211-217 */
+int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
+
+/* ---- state access ---- */
+/* UavSystem::getState — uav_system.hpp:386 / MultirotorModel::State multirotor_model.hpp:90-98.  Any pointer may be
+ * NULL.  x,v,v_prev,omega: count x 3; R: count x 9 row-major; motor_rpm: count x MRS_MAX_MOTORS. */
+int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x, double* v, double* v_prev, double* R,
+                        double* omega, double* motor_rpm);
+/* MultirotorModel::setState — multirotor_model.hpp:424-433 (v_prev untouched, like the reference) */
+int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
+                        const double* omega, const double* motor_rpm);
+/* UavSystem::getImuAcceleration — uav_system.hpp:424 */
+int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu);
+/* MultirotorModel::getExternalForce — multirotor_model.hpp:452 */
+int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, double* force);
+/* PID internals for parity checks: count x 24 = {position,velocity,attitude,rate} x {x,y,z} x {last_error, integral} */
+int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid);
+int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out);
+
+/* ---- multi-GPU collision exchange (one swarm shard per process/GPU) ---- */
+/* device pointer + byte size of this shard's packed {x,y,z,mass,arm_length,prop_radius} records (48 B/UAV), refreshed by
+ * mrs_swarm_pack_positions; the caller all-gathers them (RCCL) into a buffer of n_total records */
+int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes);
+/* handleCollisions for this shard against ALL gathered records (device pointer, n_total x 48 B);
+ * my_offset = index of this shard's first UAV in the gathered order */
+int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,
+                                         int32_t enabled, int32_t crash, double rebounce);
+
+/* last launch timing helper: average device time (ms) of the step kernel launches issued by the last
+ * mrs_swarm_step_n / mrs_swarm_tick_n call, measured with hipEvents on the swarm's stream */
+int mrs_swarm_last_step_kernel_ms(mrs_swarm_t* s, double* avg_ms, int32_t* n_launches);
+int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRS_SWARM_H */

@@ -1,0 +1,10 @@
+// FAST flavour of the fused step kernel: FMA contraction + reciprocal simplifications (-ffp-contract=fast).
+#define MRS_FAST 1
+#include "step_device.inc"
+
+extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, hipStream_t st) {
+  const int grid = (sw.n + 63) / 64;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mrs_uav_step_fast, dim3(grid), dim3(64), 0, st, sw, dt, substeps);
+  return hipGetLastError();
+}

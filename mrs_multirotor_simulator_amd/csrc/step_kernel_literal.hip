@@ -1,0 +1,10 @@
+// LITERAL flavour of the fused step kernel: reference operation order, compiled with -ffp-contract=off.
+#define MRS_FAST 0
+#include "step_device.inc"
+
+extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int substeps, hipStream_t st) {
+  const int grid = (sw.n + 63) / 64;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mrs_uav_step_literal, dim3(grid), dim3(64), 0, st, sw, dt, substeps);
+  return hipGetLastError();
+}

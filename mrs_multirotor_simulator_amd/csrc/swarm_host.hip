@@ -1,0 +1,845 @@
+// swarm_host.hip — host side of libmrs_swarm.so: the C ABI of include/mrs_swarm.h.
+//
+// Owns the device SoA state of one swarm shard, the interned per-airframe type table, the HIP stream all
+// launches go to, and the bookkeeping that turns the reference's per-UAV setters into column uploads.
+// No CPU fallback exists: without a usable HIP device mrs_swarm_create fails.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mrs_swarm.h"
+#include "swarm_layout.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int substeps, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, hipStream_t st);
+// collide.hip
+extern "C" hipError_t mrs_launch_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask, hipStream_t st);
+extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hipStream_t st);
+struct CollideWork;
+extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
+                                      int crash, double rebounce, hipStream_t st);
+extern "C" void mrs_collide_free(CollideWork* w);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return fail(MRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host-side derivations (init-time arithmetic of the reference, restated)
+// ------------------------------------------------------------------------------------------------
+
+// Eigen fixed-size 3x3 inverse(): cofactors / determinant (Eigen/src/LU/InverseImpl.h, size 3)
+static void inverse3_cofactor(const double m[9], double r[9]) {
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+  };
+  const double c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+  const double det    = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+  const double invdet = 1.0 / det;
+  r[0] = c0 * invdet;
+  r[1] = c1 * invdet;
+  r[2] = c2 * invdet;
+  r[3] = cof(0, 1) * invdet;
+  r[4] = cof(1, 1) * invdet;
+  r[5] = cof(2, 1) * invdet;
+  r[6] = cof(0, 2) * invdet;
+  r[7] = cof(1, 2) * invdet;
+  r[8] = cof(2, 2) * invdet;
+}
+
+// Eigen dynamic inverse(): PartialPivLU then solve against the identity (4x4 here)
+static void inverse_lu4(const double a[16], double out[16]) {
+  double lu[16];
+  int    perm[4] = {0, 1, 2, 3};
+  memcpy(lu, a, sizeof lu);
+  for (int k = 0; k < 4; k++) {
+    int piv = k;
+    for (int r = k + 1; r < 4; r++)
+      if (fabs(lu[r * 4 + k]) > fabs(lu[piv * 4 + k])) piv = r;
+    if (piv != k) {
+      for (int c = 0; c < 4; c++) std::swap(lu[k * 4 + c], lu[piv * 4 + c]);
+      std::swap(perm[k], perm[piv]);
+    }
+    for (int r = k + 1; r < 4; r++) {
+      lu[r * 4 + k] /= lu[k * 4 + k];
+      for (int c = k + 1; c < 4; c++) lu[r * 4 + c] -= lu[r * 4 + k] * lu[k * 4 + c];
+    }
+  }
+  for (int col = 0; col < 4; col++) {
+    double b[4];
+    for (int r = 0; r < 4; r++) b[r] = (perm[r] == col) ? 1.0 : 0.0;
+    for (int r = 1; r < 4; r++)
+      for (int c = 0; c < r; c++) b[r] -= lu[r * 4 + c] * b[c];
+    for (int r = 3; r >= 0; r--) {
+      for (int c = r + 1; c < 4; c++) b[r] -= lu[r * 4 + c] * b[c];
+      b[r] /= lu[r * 4 + r];
+    }
+    for (int r = 0; r < 4; r++) out[r * 4 + col] = b[r];
+  }
+}
+
+// Mixer::calculateAllocation — controllers/mixer.hpp:72-101
+static void mixer_allocation(const mrs_model_params_t& p, double ainv[MRS_MAXM * 4]) {
+  const int     n = p.n_motors;
+  const double* A = p.allocation_matrix;
+  double        AAt[16], AAt_inv[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < n; k++) s += A[i * MRS_MAX_MOTORS + k] * A[j * MRS_MAX_MOTORS + k];
+      AAt[i * 4 + j] = s;
+    }
+  inverse_lu4(AAt, AAt_inv);
+  memset(ainv, 0, sizeof(double) * MRS_MAXM * 4);
+  for (int m = 0; m < n; m++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < 4; k++) s += A[k * MRS_MAX_MOTORS + m] * AAt_inv[k * 4 + j];
+      ainv[m * 4 + j] = s;
+    }
+  for (int m = 0; m < n; m++) {
+    double*      r = &ainv[m * 4];
+    const double z = r[0] * r[0] + r[1] * r[1];
+    if (z > 0) {
+      const double nn = sqrt(z);
+      r[0] /= nn;
+      r[1] /= nn;
+    }
+    r[2] = (r[2] > 1e-2) ? 1.0 : ((r[2] < -1e-2) ? -1.0 : 0.0);
+    r[3] = 1.0;
+  }
+}
+
+struct TypeKey {  // everything that distinguishes two UavSystem parameterisations
+  mrs_model_params_t    mp;  // takeoff_patch_enabled normalised to 0 (it is per-UAV mutable state)
+  mrs_mixer_params_t    mixer;
+  mrs_rate_params_t     rate;
+  mrs_attitude_params_t att;
+  mrs_velocity_params_t vel;
+  mrs_position_params_t pos;
+};
+
+static void default_controllers(TypeKey& k) {  // UavSystem::initializeControllers, uav_system.hpp:159-169
+  k.mixer = mrs_mixer_params_t{1, 0};
+  k.rate  = mrs_rate_params_t{4.0, 0.04, 0.0};
+  k.att   = mrs_attitude_params_t{6.0, 0.05, 0.01, 10.0, 1.0};
+  k.vel   = mrs_velocity_params_t{2.0, 0.05, 0.01, 4.0};
+  k.pos   = mrs_position_params_t{2.0, 0.15, 0.2, 6.0};
+}
+
+static void derive_type(const TypeKey& k, double dt, TypeParams& t) {
+  const mrs_model_params_t& p = k.mp;
+  memset(&t, 0, sizeof t);
+  t.n_motors       = p.n_motors;
+  t.ground_enabled = p.ground_enabled;
+  t.desaturation   = k.mixer.desaturation;
+  t.g              = p.g;
+  t.mass           = p.mass;
+  t.inv_mass       = 1.0 / p.mass;
+  t.min_rpm        = p.min_rpm;
+  t.max_rpm        = p.max_rpm;
+  t.kf_n           = p.kf * p.n_motors;
+  t.resist_k       = p.air_resistance_coeff * M_PI * (p.arm_length) * (p.arm_length);
+  t.hover_thr      = 0.90 * sqrt((p.mass * p.g) / (p.n_motors * p.kf));
+  t.ground_z       = p.ground_z;
+  t.tau            = p.motor_time_constant;
+  t.filt_c         = exp((-dt) / (p.motor_time_constant));
+  t.filt_1mc       = 1.0 - t.filt_c;
+  t.arm_length     = p.arm_length;
+  t.prop_radius    = p.prop_radius;
+  memcpy(t.J, p.J, sizeof t.J);
+  inverse3_cofactor(p.J, t.Jinv);
+  for (int r = 0; r < 4; r++)
+    for (int m = 0; m < MRS_MAXM; m++) t.alloc[r * MRS_MAXM + m] = (m < p.n_motors) ? p.allocation_matrix[r * MRS_MAX_MOTORS + m] : 0.0;
+  mixer_allocation(p, t.alloc_inv);
+  t.pos_kp = k.pos.kp; t.pos_kd = k.pos.kd; t.pos_ki = k.pos.ki; t.pos_sat = k.pos.max_velocity;
+  t.vel_kp = k.vel.kp; t.vel_kd = k.vel.kd; t.vel_ki = k.vel.ki; t.vel_sat = k.vel.max_acceleration;
+  t.att_kp = k.att.kp; t.att_kd = k.att.kd; t.att_ki = k.att.ki;
+  t.att_sat_rp = k.att.max_rate_roll_pitch; t.att_sat_yaw = k.att.max_rate_yaw;
+  for (int i = 0; i < 3; i++) {
+    t.rate_kp[i] = k.rate.kp * p.J[i * 3 + i];
+    t.rate_kd[i] = k.rate.kd * p.J[i * 3 + i];
+    t.rate_ki[i] = k.rate.ki * p.J[i * 3 + i];
+  }
+}
+
+// Eigen::AngleAxisd(angle, UnitZ).toRotationMatrix() (Eigen/src/Geometry/AngleAxis.h), row-major out
+static void angle_axis_z(double angle, double R[9]) {
+  const double ax[3] = {0, 0, 1};
+  const double s = sin(angle), c = cos(angle);
+  const double sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+  const double ca[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+  double       tmp;
+  tmp  = ca[0] * ax[1];
+  R[1] = tmp - sa[2];
+  R[3] = tmp + sa[2];
+  tmp  = ca[0] * ax[2];
+  R[2] = tmp + sa[1];
+  R[6] = tmp - sa[1];
+  tmp  = ca[1] * ax[2];
+  R[5] = tmp - sa[0];
+  R[7] = tmp + sa[0];
+  R[0] = ca[0] * ax[0] + c;
+  R[4] = ca[1] * ax[1] + c;
+  R[8] = ca[2] * ax[2] + c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// swarm object
+// ------------------------------------------------------------------------------------------------
+
+struct mrs_swarm {
+  int32_t  n = 0, npad = 0, device = 0;
+  int32_t  arith = MRS_ARITH_LITERAL;
+  hipStream_t stream = nullptr;
+  double*   dS = nullptr;
+  uint32_t* dF = nullptr;
+  TypeParams* dT = nullptr;
+  int32_t   dT_cap = 0;
+  unsigned long long* dDiag = nullptr;
+  std::vector<TypeKey>    keys;
+  std::vector<TypeParams> tparams;
+  std::map<std::string, int> key_index;
+  std::vector<uint16_t>   uav_type;
+  bool   types_dirty = true;
+  double table_dt    = -1.0;
+  // collision scratch
+  PosRecord*   dRec = nullptr;
+  CollideWork* cwork = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  int  ev_used = 0;
+  double last_ms = 0.0;
+  int    last_launches = 0;
+  std::vector<double>   stage;  // host staging column
+  std::vector<uint32_t> stage_u;
+
+  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, n, npad}; }
+};
+
+static int check_range(const mrs_swarm* s, int first, int count) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (first < 0 || count < 0 || (long long)first + count > s->n) return fail(MRS_ERR_RANGE, "uav range out of bounds");
+  return MRS_OK;
+}
+
+static int intern_type(mrs_swarm* s, const TypeKey& k, int* out) {
+  std::string bytes(reinterpret_cast<const char*>(&k), sizeof k);
+  auto        it = s->key_index.find(bytes);
+  if (it != s->key_index.end()) {
+    *out = it->second;
+    return MRS_OK;
+  }
+  if ((int)s->keys.size() >= MRS_MAX_TYPES) return fail(MRS_ERR_TYPES, "type table full (65536 distinct parameter sets)");
+  s->keys.push_back(k);
+  TypeParams t;
+  derive_type(k, s->table_dt > 0 ? s->table_dt : 0.001, t);
+  s->tparams.push_back(t);
+  *out = (int)s->keys.size() - 1;
+  s->key_index.emplace(std::move(bytes), *out);
+  s->types_dirty = true;
+  return MRS_OK;
+}
+
+static TypeKey make_key(const mrs_model_params_t* p) {
+  TypeKey k;
+  memset(&k, 0, sizeof k);  // deterministic padding bytes: the key is compared bytewise
+  if (p)
+    memcpy(&k.mp, p, sizeof k.mp);
+  else
+    mrs_model_params_default(&k.mp);
+  k.mp.takeoff_patch_enabled = 0;
+  k.mp._pad                  = 0;
+  for (int r = 0; r < 4; r++)  // unused motor columns must not split types
+    for (int m = k.mp.n_motors; m < MRS_MAX_MOTORS; m++) k.mp.allocation_matrix[r * MRS_MAX_MOTORS + m] = 0.0;
+  default_controllers(k);
+  return k;
+}
+
+static int upload_types(mrs_swarm* s, double dt) {
+  if (!s->types_dirty && dt == s->table_dt) return MRS_OK;
+  if (dt != s->table_dt) {
+    for (size_t i = 0; i < s->keys.size(); i++) {
+      s->tparams[i].filt_c   = exp((-dt) / (s->keys[i].mp.motor_time_constant));  // multirotor_model.hpp:244
+      s->tparams[i].filt_1mc = 1.0 - s->tparams[i].filt_c;
+    }
+    s->table_dt = dt;
+  }
+  const int need = (int)s->tparams.size();
+  if (need > s->dT_cap) {
+    // the old table may still be read by launches in flight on the stream
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->dT) HIPCHK(hipFree(s->dT));
+    int cap = 16;
+    while (cap < need) cap *= 2;
+    HIPCHK(hipMalloc(&s->dT, sizeof(TypeParams) * (size_t)cap));
+    s->dT_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(s->dT, s->tparams.data(), sizeof(TypeParams) * (size_t)need, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));  // tparams (pageable) may change right after we return
+  s->types_dirty = false;
+  return MRS_OK;
+}
+
+// upload one column (count doubles from the staging vector) into field f at [first, first+count)
+static int put_column(mrs_swarm* s, int f, int first, int count, const double* col) {
+  HIPCHK(hipMemcpyAsync(s->dS + (size_t)f * s->npad + first, col, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return MRS_OK;
+}
+static int fill_column(mrs_swarm* s, int f, int first, int count, double value) {
+  if (value == 0.0) {
+    HIPCHK(hipMemsetAsync(s->dS + (size_t)f * s->npad + first, 0, sizeof(double) * (size_t)count, s->stream));
+    return MRS_OK;
+  }
+  s->stage.assign((size_t)count, value);
+  return put_column(s, f, first, count, s->stage.data());
+}
+// host AoS (count x width, element j) -> device column
+static int put_strided(mrs_swarm* s, int f, int first, int count, const double* src, int width, int j) {
+  s->stage.resize((size_t)count);
+  for (int k = 0; k < count; k++) s->stage[(size_t)k] = src[(size_t)k * width + j];
+  return put_column(s, f, first, count, s->stage.data());
+}
+static int get_strided(mrs_swarm* s, int f, int first, int count, double* dst, int width, int j) {
+  s->stage.resize((size_t)count);
+  HIPCHK(hipMemcpyAsync(s->stage.data(), s->dS + (size_t)f * s->npad + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost,
+                        s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for (int k = 0; k < count; k++) dst[(size_t)k * width + j] = s->stage[(size_t)k];
+  return MRS_OK;
+}
+static int flags_update(mrs_swarm* s, int first, int count, uint32_t and_mask, uint32_t or_mask) {
+  if (count <= 0) return MRS_OK;
+  HIPCHK(mrs_launch_flags_update(s->dF, first, count, and_mask, or_mask, s->stream));
+  return MRS_OK;
+}
+
+// shared body of the five controller-parameter setters: re-intern the type of every UAV in the range with one
+// member of its key replaced, zero that controller's PID columns (pid_field < 0: the mixer has none)
+template <class Mutator>
+static int set_controller_params(mrs_swarm* s, int first, int count, int pid_field, Mutator mutate) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  std::map<int, int> remap;
+  int                run_start = first, run_type = -1;
+  for (int k = 0; k <= count; k++) {
+    int nt = -1;
+    if (k < count) {
+      const int old = s->uav_type[(size_t)first + k];
+      auto      it  = remap.find(old);
+      if (it == remap.end()) {
+        TypeKey key = s->keys[(size_t)old];
+        mutate(key);
+        if ((rc = intern_type(s, key, &nt))) return rc;
+        remap[old] = nt;
+      } else {
+        nt = it->second;
+      }
+      s->uav_type[(size_t)first + k] = (uint16_t)nt;
+    }
+    if (k == count || nt != run_type) {
+      if (run_type >= 0 && (rc = flags_update(s, run_start, first + k - run_start, ~(0xFFFFu << FLAG_TYPE_SHIFT), (uint32_t)run_type << FLAG_TYPE_SHIFT)))
+        return rc;
+      run_start = first + k;
+      run_type  = nt;
+    }
+  }
+  if (pid_field >= 0)
+    for (int f = pid_field; f < pid_field + 6; f++)
+      if ((rc = fill_column(s, f, first, count, 0.0))) return rc;
+  return MRS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mrs_last_error(void) { return g_err.c_str(); }
+
+int mrs_calculate_inertia(mrs_model_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  memset(p->J, 0, sizeof p->J);
+  p->J[0] = p->mass * (3.0 * p->arm_length * p->arm_length + p->body_height * p->body_height) / 12.0;
+  p->J[4] = p->mass * (3.0 * p->arm_length * p->arm_length + p->body_height * p->body_height) / 12.0;
+  p->J[8] = (p->mass * p->arm_length * p->arm_length) / 2.0;
+  return MRS_OK;
+}
+
+int mrs_scale_allocation(mrs_model_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  if (p->n_motors < 1 || p->n_motors > MRS_MAX_MOTORS) return fail(MRS_ERR_ARG, "n_motors must be 1..8");
+  for (int m = 0; m < p->n_motors; m++) {
+    p->allocation_matrix[0 * MRS_MAX_MOTORS + m] *= p->arm_length * p->kf;
+    p->allocation_matrix[1 * MRS_MAX_MOTORS + m] *= p->arm_length * p->kf;
+    p->allocation_matrix[2 * MRS_MAX_MOTORS + m] *= p->km * (3.0 * p->prop_radius) * p->kf;
+    p->allocation_matrix[3 * MRS_MAX_MOTORS + m] *= p->kf;
+  }
+  return MRS_OK;
+}
+
+int mrs_model_params_default(mrs_model_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  static const double a[4][4] = {{-0.707, 0.707, 0.707, -0.707}, {-0.707, 0.707, -0.707, 0.707}, {-1, -1, 1, 1}, {1, 1, 1, 1}};
+  memset(p, 0, sizeof *p);
+  p->n_motors             = 4;
+  p->g                    = 9.81;
+  p->mass                 = 2.0;
+  p->kf                   = 0.00000027087;
+  p->km                   = 0.07;
+  p->prop_radius          = 0.15;
+  p->arm_length           = 0.25;
+  p->body_height          = 0.1;
+  p->motor_time_constant  = 0.03;
+  p->max_rpm              = 7800;
+  p->min_rpm              = 1170;
+  p->air_resistance_coeff = 0.30;
+  mrs_calculate_inertia(p);
+  for (int r = 0; r < 4; r++)
+    for (int m = 0; m < 4; m++) p->allocation_matrix[r * MRS_MAX_MOTORS + m] = a[r][m];
+  mrs_scale_allocation(p);
+  p->ground_enabled        = 0;
+  p->ground_z              = 0.0;
+  p->takeoff_patch_enabled = 1;
+  return MRS_OK;
+}
+
+int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
+  if (!out || n_uavs < 0) return fail(MRS_ERR_ARG, "bad arguments");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MRS_ERR_HIP, "no HIP device available: libmrs_swarm has no CPU fallback");
+  if (device_id < 0) HIPCHK(hipGetDevice(&device_id));
+  if (device_id >= ndev) return fail(MRS_ERR_ARG, "device_id out of range");
+  HIPCHK(hipSetDevice(device_id));
+  mrs_swarm* s = new mrs_swarm();
+  s->n         = n_uavs;
+  s->npad      = ((n_uavs + 63) / 64) * 64;
+  if (s->npad == 0) s->npad = 64;
+  s->device = device_id;
+  HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&s->dS, sizeof(double) * (size_t)F_COUNT * s->npad));
+  HIPCHK(hipMalloc(&s->dF, sizeof(uint32_t) * (size_t)s->npad));
+  HIPCHK(hipMalloc(&s->dDiag, sizeof(unsigned long long) * 4));
+  HIPCHK(hipMemsetAsync(s->dS, 0, sizeof(double) * (size_t)F_COUNT * s->npad, s->stream));
+  HIPCHK(hipMemsetAsync(s->dF, 0, sizeof(uint32_t) * (size_t)s->npad, s->stream));
+  HIPCHK(hipMemsetAsync(s->dDiag, 0, sizeof(unsigned long long) * 4, s->stream));
+  s->uav_type.assign((size_t)s->npad, 0);
+  *out = s;
+  if (n_uavs > 0) {
+    int rc = mrs_swarm_construct(s, 0, n_uavs, nullptr, nullptr, nullptr);
+    if (rc != MRS_OK) return rc;
+  }
+  return MRS_OK;
+}
+
+int mrs_swarm_destroy(mrs_swarm_t* s) {
+  if (!s) return MRS_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  for (auto e : s->ev) (void)hipEventDestroy(e);
+  mrs_collide_free(s->cwork);
+  if (s->dRec) (void)hipFree(s->dRec);
+  if (s->dT) (void)hipFree(s->dT);
+  (void)hipFree(s->dDiag);
+  (void)hipFree(s->dF);
+  (void)hipFree(s->dS);
+  (void)hipStreamDestroy(s->stream);
+  delete s;
+  return MRS_OK;
+}
+
+int mrs_swarm_size(const mrs_swarm_t* s, int32_t* n) {
+  if (!s || !n) return fail(MRS_ERR_ARG, "null argument");
+  *n = s->n;
+  return MRS_OK;
+}
+
+int mrs_swarm_set_arith(mrs_swarm_t* s, int32_t arith) {
+  if (!s || (arith != MRS_ARITH_LITERAL && arith != MRS_ARITH_FAST)) return fail(MRS_ERR_ARG, "bad arith");
+  s->arith = arith;
+  return MRS_OK;
+}
+
+int mrs_swarm_stream(const mrs_swarm_t* s, void** stream) {
+  if (!s || !stream) return fail(MRS_ERR_ARG, "null argument");
+  *stream = (void*)s->stream;
+  return MRS_OK;
+}
+
+int mrs_swarm_synchronize(mrs_swarm_t* s) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return MRS_OK;
+}
+
+int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params, const double* pos,
+                        const double* heading) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  if (params && (params->n_motors < 1 || params->n_motors > MRS_MAX_MOTORS)) return fail(MRS_ERR_ARG, "n_motors must be 1..8");
+  HIPCHK(hipSetDevice(s->device));
+  TypeKey key = make_key(params);
+  int     type;
+  if ((rc = intern_type(s, key, &type))) return rc;
+  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type;
+  // MultirotorModel::initializeState (multirotor_model.hpp:183-198): everything zero, R = I
+  for (int f = 0; f < F_COUNT; f++) {
+    const bool diag = (f == F_R + 0 || f == F_R + 4 || f == F_R + 8);
+    if ((rc = fill_column(s, f, first, count, diag ? 1.0 : 0.0))) return rc;
+  }
+  if (pos) {  // MultirotorModel::setStatePos, multirotor_model.hpp:439-446
+    for (int j = 0; j < 3; j++)
+      if ((rc = put_strided(s, F_X + j, first, count, pos, 3, j))) return rc;
+    if ((rc = put_strided(s, F_INITZ, first, count, pos, 3, 2))) return rc;
+    std::vector<double> Rm((size_t)count * 9);
+    for (int k = 0; k < count; k++) angle_axis_z(-(heading ? heading[k] : 0.0), &Rm[(size_t)k * 9]);
+    for (int j = 0; j < 9; j++)
+      if ((rc = put_strided(s, F_R + j, first, count, Rm.data(), 9, j))) return rc;
+  }
+  const int      takeoff = params ? params->takeoff_patch_enabled : 1;
+  const uint32_t flags   = (takeoff ? FLAG_TAKEOFF : 0u) | ((uint32_t)MRS_INPUT_UNKNOWN << FLAG_MODE_SHIFT) | ((uint32_t)type << FLAG_TYPE_SHIFT);
+  return flags_update(s, first, count, 0u, flags);
+}
+
+int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!params || params->n_motors < 1 || params->n_motors > MRS_MAX_MOTORS) return fail(MRS_ERR_ARG, "bad params");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  TypeKey key = make_key(params);  // default gains: initializeControllers(), uav_system.hpp:404-409
+  int     type;
+  if ((rc = intern_type(s, key, &type))) return rc;
+  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type;
+  for (int f = F_PID; f < F_PID + 24; f++)
+    if ((rc = fill_column(s, f, first, count, 0.0))) return rc;
+  return flags_update(s, first, count, ~((0xFFFFu << FLAG_TYPE_SHIFT) | FLAG_TAKEOFF),
+                      ((uint32_t)type << FLAG_TYPE_SHIFT) | (params->takeoff_patch_enabled ? FLAG_TAKEOFF : 0u));
+}
+
+int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out) {
+  int rc = check_range(s, uav, 1);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  HIPCHK(hipSetDevice(s->device));
+  *out = s->keys[s->uav_type[(size_t)uav]].mp;
+  uint32_t fl = 0;
+  HIPCHK(hipMemcpyAsync(&fl, s->dF + uav, sizeof fl, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  out->takeoff_patch_enabled = (fl & FLAG_TAKEOFF) ? 1 : 0;
+  return MRS_OK;
+}
+
+int mrs_swarm_set_mixer_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_mixer_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  const mrs_mixer_params_t v{p->desaturation ? 1 : 0, 0};
+  return set_controller_params(s, first, count, -1, [&](TypeKey& k) { k.mixer = v; });
+}
+int mrs_swarm_set_position_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_position_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  return set_controller_params(s, first, count, F_PID + 0, [&](TypeKey& k) { k.pos = *p; });
+}
+int mrs_swarm_set_velocity_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_velocity_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  return set_controller_params(s, first, count, F_PID + 6, [&](TypeKey& k) { k.vel = *p; });
+}
+int mrs_swarm_set_attitude_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_attitude_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  return set_controller_params(s, first, count, F_PID + 12, [&](TypeKey& k) { k.att = *p; });
+}
+int mrs_swarm_set_rate_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_rate_params_t* p) {
+  if (!p) return fail(MRS_ERR_ARG, "null params");
+  return set_controller_params(s, first, count, F_PID + 18, [&](TypeKey& k) { k.rate = *p; });
+}
+
+int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
+  int rc = check_range(s, uav, 1);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  const TypeParams& t = s->tparams[s->uav_type[(size_t)uav]];
+  memcpy(out, t.alloc_inv, sizeof(double) * 4 * (size_t)t.n_motors);
+  return MRS_OK;
+}
+
+int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (mode < MRS_INPUT_UNKNOWN || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int width = 0;
+  switch (mode) {
+    case MRS_INPUT_UNKNOWN: width = 0; break;
+    case MRS_ACTUATOR_CMD: width = stride < MRS_MAX_MOTORS ? stride : MRS_MAX_MOTORS; break;
+    case MRS_ATTITUDE_CMD: width = 10; break;
+    case MRS_TILT_HDG_RATE_CMD: width = 5; break;
+    default: width = 4; break;
+  }
+  if (width > 0 && (!payload || stride < width)) return fail(MRS_ERR_ARG, "payload missing or stride too small for this mode");
+  if (mode == MRS_ACTUATOR_CMD) {
+    for (int k = 0; k < count; k++)
+      if (s->keys[s->uav_type[(size_t)first + k]].mp.n_motors > width)
+        return fail(MRS_ERR_ARG, "actuator payload narrower than n_motors");
+  }
+  for (int j = 0; j < width; j++)
+    if ((rc = put_strided(s, F_CMD + j, first, count, payload, stride, j))) return rc;
+  return flags_update(s, first, count, ~FLAG_MODE_MASK, (uint32_t)mode << FLAG_MODE_SHIFT);
+}
+
+int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (kind < 0 || kind > 3 || !payload || stride < 4) return fail(MRS_ERR_ARG, "bad feed-forward arguments");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 4; j++)
+    if ((rc = put_strided(s, F_FF + 4 * kind + j, first, count, payload, stride, j))) return rc;
+  return flags_update(s, first, count, ~0u, (1u << kind) << FLAG_FF_SHIFT);
+}
+
+int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const double* force) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!force) return fail(MRS_ERR_ARG, "null force");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 3; j++)
+    if ((rc = put_strided(s, F_FEXT + j, first, count, force, 3, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  return flags_update(s, first, count, ~0u, FLAG_CRASHED);
+}
+
+int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  s->stage_u.resize((size_t)count);
+  HIPCHK(hipMemcpyAsync(s->stage_u.data(), s->dF + first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for (int k = 0; k < count; k++) out[k] = (s->stage_u[(size_t)k] & FLAG_CRASHED) ? 1 : 0;
+  return MRS_OK;
+}
+
+// ---- hot path ----
+static int launch_step(mrs_swarm* s, double dt, int substeps) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (s->profiling) {
+    while ((int)s->ev.size() < s->ev_used + 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      s->ev.push_back(e);
+    }
+    e0 = s->ev[(size_t)s->ev_used];
+    e1 = s->ev[(size_t)s->ev_used + 1];
+    s->ev_used += 2;
+    HIPCHK(hipEventRecord(e0, s->stream));
+  }
+  if (s->arith == MRS_ARITH_FAST)
+    HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, s->stream));
+  else
+    HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, s->stream));
+  if (s->profiling) HIPCHK(hipEventRecord(e1, s->stream));
+  return MRS_OK;
+}
+
+static int finish_profile(mrs_swarm* s) {
+  if (!s->profiling || s->ev_used == 0) return MRS_OK;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  double total = 0;
+  for (int k = 0; k < s->ev_used; k += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[(size_t)k], s->ev[(size_t)k + 1]));
+    total += ms;
+  }
+  s->last_launches = s->ev_used / 2;
+  s->last_ms       = total / s->last_launches;
+  s->ev_used       = 0;
+  return MRS_OK;
+}
+
+int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substeps_per_launch) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!(dt > 0) || n_steps < 0 || substeps_per_launch < 1) return fail(MRS_ERR_ARG, "bad step arguments");
+  if (s->n == 0 || n_steps == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, dt);
+  if (rc) return rc;
+  s->ev_used = 0;
+  int left = n_steps;
+  while (left > 0) {
+    const int sub = left < substeps_per_launch ? left : substeps_per_launch;
+    if ((rc = launch_step(s, dt, sub))) return rc;
+    left -= sub;
+  }
+  return finish_profile(s);
+}
+
+int mrs_swarm_step(mrs_swarm_t* s, double dt) { return mrs_swarm_step_n(s, dt, 1, 1); }
+
+int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
+  if (rc) return rc;
+  if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
+  HIPCHK(mrs_launch_pack_positions(s->view(), s->dRec, s->stream));
+  if (dev_ptr) *dev_ptr = s->dRec;
+  if (n_bytes) *n_bytes = (int64_t)sizeof(PosRecord) * s->n;
+  return MRS_OK;
+}
+
+int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset, int32_t enabled,
+                                         int32_t crash, double rebounce) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
+  if (!dev_records || n_total < s->n || my_offset < 0 || my_offset + s->n > n_total) return fail(MRS_ERR_ARG, "bad gathered-record arguments");
+  if (s->n == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, s->stream));
+  return MRS_OK;
+}
+
+int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, double rebounce) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!(crash || enabled)) return MRS_OK;
+  if (s->n == 0) return MRS_OK;
+  int rc = mrs_swarm_pack_positions(s, nullptr, nullptr);
+  if (rc) return rc;
+  return mrs_swarm_handle_collisions_gathered(s, s->dRec, s->n, 0, enabled, crash, rebounce);
+}
+
+int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
+  if (s->n == 0 || n_ticks == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, dt);
+  if (rc) return rc;
+  s->ev_used = 0;
+  for (int k = 0; k < n_ticks; k++) {
+    if ((rc = launch_step(s, dt, 1))) return rc;
+    if ((rc = mrs_swarm_handle_collisions(s, enabled, crash, rebounce))) return rc;
+  }
+  return finish_profile(s);
+}
+
+// ---- state access ----
+int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x, double* v, double* v_prev, double* R, double* omega,
+                        double* motor_rpm) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  struct { double* p; int f, w; } items[6] = {{x, F_X, 3}, {v, F_V, 3}, {v_prev, F_VPREV, 3}, {R, F_R, 9}, {omega, F_W, 3}, {motor_rpm, F_RPM, MRS_MAX_MOTORS}};
+  for (auto& it : items)
+    if (it.p)
+      for (int j = 0; j < it.w; j++)
+        if ((rc = get_strided(s, it.f + j, first, count, it.p, it.w, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
+                        const double* omega, const double* motor_rpm) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  struct { const double* p; int f, w; } items[5] = {{x, F_X, 3}, {v, F_V, 3}, {R, F_R, 9}, {omega, F_W, 3}, {motor_rpm, F_RPM, MRS_MAX_MOTORS}};
+  for (auto& it : items)
+    if (it.p)
+      for (int j = 0; j < it.w; j++)
+        if ((rc = put_strided(s, it.f + j, first, count, it.p, it.w, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!imu) return fail(MRS_ERR_ARG, "null out");
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 3 && count > 0; j++)
+    if ((rc = get_strided(s, F_IMU + j, first, count, imu, 3, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, double* force) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!force) return fail(MRS_ERR_ARG, "null out");
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 3 && count > 0; j++)
+    if ((rc = get_strided(s, F_FEXT + j, first, count, force, 3, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!pid) return fail(MRS_ERR_ARG, "null out");
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 24 && count > 0; j++)
+    if ((rc = get_strided(s, F_PID + j, first, count, pid, 24, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
+  if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(s->device));
+  unsigned long long d[4];
+  HIPCHK(hipMemcpyAsync(d, s->dDiag, sizeof d, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  out->hdg_rate_denom_small = d[0];
+  out->projected_norm_small = d[1];
+  out->yaw_rate_not_finite  = d[2];
+  out->nan_rollback         = d[3];
+  return MRS_OK;
+}
+
+int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  s->profiling = enabled != 0;
+  return MRS_OK;
+}
+
+int mrs_swarm_last_step_kernel_ms(mrs_swarm_t* s, double* avg_ms, int32_t* n_launches) {
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (avg_ms) *avg_ms = s->last_ms;
+  if (n_launches) *n_launches = s->last_launches;
+  return MRS_OK;
+}
+
+}  // extern "C"

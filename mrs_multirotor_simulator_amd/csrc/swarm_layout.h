@@ -1,0 +1,75 @@
+// swarm_layout.h — device data layout shared by the host library and the kernels.
+//
+// State lives in HBM as field-major SoA FP64: S[field * npad + uav] (npad = n rounded up to 64), so
+// lane l of a wavefront reads uav base+l of every field with one coalesced 512-B request.  Per-UAV
+// flags are one u32.  Per-airframe constants ("types") sit in a small table that the step kernel
+// reads through the scalar cache (one type per wavefront iteration — see step_device.inc).
+#pragma once
+#include <stdint.h>
+
+#define MRS_MAXM 8
+
+// ---- SoA field indices (doubles) ----
+enum {
+  F_X     = 0,   // 3  position                      MultirotorModel::State::x      multirotor_model.hpp:92
+  F_V     = 3,   // 3  velocity                                     ::v                                   :93
+  F_VPREV = 6,   // 3                                               ::v_prev                              :94
+  F_R     = 9,   // 9  rotation matrix, row-major                   ::R                                   :95
+  F_W     = 18,  // 3  body rates                                   ::omega                               :96
+  F_RPM   = 21,  // 8  motor rpm (first n_motors used)              ::motor_rpm                           :97
+  F_IMU   = 29,  // 3  imu_acceleration_                                                                  :139
+  F_FEXT  = 32,  // 3  external_force_                                                                    :142
+  F_INITZ = 35,  // 1  _initial_pos_(2)                                                                   :145
+  F_PID   = 36,  // 24 {position,velocity,attitude,rate} x {x,y,z} x {last_error_, integral_}  pid.hpp:20-21
+  F_CMD   = 60,  // 10 payload of the active input (layout per mode, see mrs_swarm.h)   uav_system.hpp:99-108
+  F_FF    = 70,  // 16 four feed-forward slots x {vec3, heading(_rate)}                 uav_system.hpp:112-115
+  F_COUNT = 86
+};
+
+// ---- per-UAV flag word ----
+#define FLAG_CRASHED   0x1u        // UavSystem::crashed_                    uav_system.hpp:80
+#define FLAG_TAKEOFF   0x2u        // params_.takeoff_patch_enabled (mutated by step())  multirotor_model.hpp:264-276
+#define FLAG_MODE_SHIFT 2          // 4 bits: UavSystem::active_input_       uav_system.hpp:95
+#define FLAG_MODE_MASK (0xFu << FLAG_MODE_SHIFT)
+#define FLAG_FF_SHIFT  6           // 4 bits: which std::optional feed-forwards hold a value
+#define FLAG_FF_MASK   (0xFu << FLAG_FF_SHIFT)
+#define FLAG_TYPE_SHIFT 16         // 16 bits: index into the type table
+#define MRS_MAX_TYPES  65536
+
+// ---- per-type constants (device copy; everything the kernels need, pre-derived on the host with the
+//      reference's own operation order so the values are bit-identical to computing them per step) ----
+struct TypeParams {
+  int32_t n_motors, ground_enabled, desaturation, _pad;
+  double  g, mass, inv_mass, min_rpm, max_rpm;
+  double  kf_n;       // kf * n_motors                                  acceleration_controller.hpp:92
+  double  resist_k;   // ((air_resistance_coeff * M_PI) * arm) * arm    multirotor_model.hpp:337 (prefix of the product chain)
+  double  hover_thr;  // 0.90 * sqrt((mass*g)/(n_motors*kf))            multirotor_model.hpp:266-267
+  double  ground_z;
+  double  filt_c;     // exp(-dt/motor_time_constant) for the dt of the current launch   :244
+  double  filt_1mc;   // 1.0 - filt_c
+  double  tau;        // motor_time_constant
+  double  arm_length, prop_radius;  // collision criterion             src/multirotor_simulator.cpp:342
+  double  J[9], Jinv[9];            // Jinv = Eigen 3x3 cofactor inverse of J     multirotor_model.hpp:350
+  double  alloc[4 * MRS_MAXM];      // torque/thrust allocation, row-major 4 x 8  :334
+  double  alloc_inv[MRS_MAXM * 4];  // Mixer::allocation_matrix_inv_, n x 4       mixer.hpp:72-101
+  double  pos_kp, pos_kd, pos_ki, pos_sat;                 // position_controller.hpp:92-103
+  double  vel_kp, vel_kd, vel_ki, vel_sat;                 // velocity_controller.hpp:108-119
+  double  att_kp, att_kd, att_ki, att_sat_rp, att_sat_yaw; // attitude_controller.hpp:160-171
+  double  rate_kp[3], rate_kd[3], rate_ki[3];              // gains * J(i,i), rate_controller.hpp:56-65
+};
+
+// ---- device view of a swarm ----
+struct SwarmDev {
+  double*             S;      // F_COUNT x npad
+  uint32_t*           F;      // npad
+  const TypeParams*   T;      // type table
+  unsigned long long* diag;   // 4 counters (mrs_diag_t order)
+  int32_t             n, npad;
+};
+
+// 48-byte record exchanged for the collision pass (single- and multi-GPU): everything
+// MultirotorSimulator::handleCollisions reads of the partner UAV (src/multirotor_simulator.cpp:339-350)
+struct PosRecord {
+  double x, y, z;
+  double mass, arm_length, prop_radius;
+};

@@ -1,0 +1,309 @@
+"""ctypes mirror of include/mrs_swarm.h: `Swarm` is a whole fleet of the reference's UavSystem objects
+resident on one MI355X.  Method names follow the reference API (setInput -> set_input, makeStep -> step, ...).
+There is no CPU fallback: a missing libmrs_swarm.so or a missing GPU raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmrs_swarm.so")
+MAX_MOTORS = 8
+
+(INPUT_UNKNOWN, ACTUATOR_CMD, CONTROL_GROUP_CMD, ATTITUDE_RATE_CMD, ATTITUDE_CMD, TILT_HDG_RATE_CMD,
+ ACCELERATION_HDG_RATE_CMD, ACCELERATION_HDG_CMD, VELOCITY_HDG_RATE_CMD, VELOCITY_HDG_CMD, POSITION_CMD) = range(11)
+FF_VELOCITY_HDG_RATE, FF_VELOCITY_HDG, FF_ACCELERATION_HDG_RATE, FF_ACCELERATION_HDG = range(4)
+ARITH_LITERAL, ARITH_FAST = 0, 1
+
+
+class MrsError(RuntimeError):
+    pass
+
+
+class ModelParams(C.Structure):
+    """mrs_model_params_t == MultirotorModel::ModelParams (multirotor_model.hpp:24-88)."""
+    _fields_ = [("n_motors", C.c_int32), ("ground_enabled", C.c_int32), ("takeoff_patch_enabled", C.c_int32),
+                ("_pad", C.c_int32)] + [(k, C.c_double) for k in (
+                    "g", "mass", "kf", "km", "prop_radius", "arm_length", "body_height", "motor_time_constant",
+                    "max_rpm", "min_rpm", "air_resistance_coeff", "ground_z")] + [
+                        ("J", C.c_double * 9), ("allocation_matrix", C.c_double * (4 * MAX_MOTORS))]
+
+
+class MixerParams(C.Structure):
+    _fields_ = [("desaturation", C.c_int32), ("_pad", C.c_int32)]
+
+
+class RateParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("kp", "kd", "ki")]
+
+
+class AttitudeParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("kp", "kd", "ki", "max_rate_roll_pitch", "max_rate_yaw")]
+
+
+class VelocityParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("kp", "kd", "ki", "max_acceleration")]
+
+
+class PositionParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("kp", "kd", "ki", "max_velocity")]
+
+
+class Diag(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("hdg_rate_denom_small", "projected_norm_small", "yaw_rate_not_finite",
+                                          "nan_rollback")]
+
+
+# every symbol include/mrs_swarm.h declares
+ABI_SYMBOLS = [
+    "mrs_model_params_default", "mrs_calculate_inertia", "mrs_scale_allocation", "mrs_swarm_create",
+    "mrs_swarm_destroy", "mrs_swarm_size", "mrs_swarm_set_arith", "mrs_swarm_stream", "mrs_swarm_synchronize",
+    "mrs_last_error", "mrs_swarm_construct", "mrs_swarm_set_params", "mrs_swarm_get_params",
+    "mrs_swarm_set_mixer_params", "mrs_swarm_set_rate_params", "mrs_swarm_set_attitude_params",
+    "mrs_swarm_set_velocity_params", "mrs_swarm_set_position_params", "mrs_swarm_get_mixer_allocation",
+    "mrs_swarm_set_input", "mrs_swarm_set_feedforward", "mrs_swarm_apply_force", "mrs_swarm_crash",
+    "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
+    "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
+    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_pack_positions", "mrs_swarm_handle_collisions_gathered",
+    "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree libmrs_swarm.so (built by mrs_multirotor_simulator_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrsError(f"{LIB_PATH} is missing: run `python -m mrs_multirotor_simulator_amd.build` "
+                       "(the HIP extension is the only implementation; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    i32, f64 = C.c_int32, C.c_double
+    sig = {
+        "mrs_model_params_default": [C.POINTER(ModelParams)],
+        "mrs_calculate_inertia": [C.POINTER(ModelParams)],
+        "mrs_scale_allocation": [C.POINTER(ModelParams)],
+        "mrs_swarm_create": [i32, i32, C.POINTER(vp)],
+        "mrs_swarm_destroy": [vp],
+        "mrs_swarm_size": [vp, ip],
+        "mrs_swarm_set_arith": [vp, i32],
+        "mrs_swarm_stream": [vp, C.POINTER(vp)],
+        "mrs_swarm_synchronize": [vp],
+        "mrs_swarm_construct": [vp, i32, i32, C.POINTER(ModelParams), dp, dp],
+        "mrs_swarm_set_params": [vp, i32, i32, C.POINTER(ModelParams)],
+        "mrs_swarm_get_params": [vp, i32, C.POINTER(ModelParams)],
+        "mrs_swarm_set_mixer_params": [vp, i32, i32, C.POINTER(MixerParams)],
+        "mrs_swarm_set_rate_params": [vp, i32, i32, C.POINTER(RateParams)],
+        "mrs_swarm_set_attitude_params": [vp, i32, i32, C.POINTER(AttitudeParams)],
+        "mrs_swarm_set_velocity_params": [vp, i32, i32, C.POINTER(VelocityParams)],
+        "mrs_swarm_set_position_params": [vp, i32, i32, C.POINTER(PositionParams)],
+        "mrs_swarm_get_mixer_allocation": [vp, i32, dp],
+        "mrs_swarm_set_input": [vp, i32, i32, i32, dp, i32],
+        "mrs_swarm_set_feedforward": [vp, i32, i32, i32, dp, i32],
+        "mrs_swarm_apply_force": [vp, i32, i32, dp],
+        "mrs_swarm_crash": [vp, i32, i32],
+        "mrs_swarm_has_crashed": [vp, i32, i32, ip],
+        "mrs_swarm_step": [vp, f64],
+        "mrs_swarm_step_n": [vp, f64, i32, i32],
+        "mrs_swarm_handle_collisions": [vp, i32, i32, f64],
+        "mrs_swarm_tick_n": [vp, f64, i32, i32, i32, f64],
+        "mrs_swarm_get_state": [vp, i32, i32, dp, dp, dp, dp, dp, dp],
+        "mrs_swarm_set_state": [vp, i32, i32, dp, dp, dp, dp, dp],
+        "mrs_swarm_get_imu": [vp, i32, i32, dp],
+        "mrs_swarm_get_external_force": [vp, i32, i32, dp],
+        "mrs_swarm_get_pid": [vp, i32, i32, dp],
+        "mrs_swarm_get_diag": [vp, C.POINTER(Diag)],
+        "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
+        "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
+        "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
+        "mrs_swarm_set_profiling": [vp, i32],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.mrs_last_error.restype = C.c_char_p
+    L.mrs_last_error.argtypes = []
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise MrsError(f"libmrs_swarm error {rc}: {load_library().mrs_last_error().decode()}")
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _arr(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+def default_params():
+    """ModelParams() of the reference: x500 defaults (multirotor_model.hpp:26-66)."""
+    p = ModelParams()
+    _check(load_library().mrs_model_params_default(C.byref(p)))
+    return p
+
+
+class Swarm:
+    """n UavSystem objects on one GPU (SoA FP64 state in HBM); every method maps to one C-ABI call."""
+
+    def __init__(self, n, device=-1, arith=ARITH_LITERAL):
+        self._h = C.c_void_p()
+        self.n = int(n)
+        _check(load_library().mrs_swarm_create(self.n, device, C.byref(self._h)))
+        self.set_arith(arith)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().mrs_swarm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters --
+    def set_arith(self, arith):
+        _check(_lib.mrs_swarm_set_arith(self._h, arith))
+
+    def construct(self, first, count, params=None, pos=None, heading=None):
+        pos, heading = _arr(pos, (count, 3)), _arr(heading, (count,))
+        _check(_lib.mrs_swarm_construct(self._h, first, count, C.byref(params) if params is not None else None, _dp(pos),
+                                        _dp(heading)))
+
+    def set_params(self, first, count, params):
+        _check(_lib.mrs_swarm_set_params(self._h, first, count, C.byref(params)))
+
+    def get_params(self, uav):
+        p = ModelParams()
+        _check(_lib.mrs_swarm_get_params(self._h, uav, C.byref(p)))
+        return p
+
+    def set_mixer_params(self, first, count, desaturation=True):
+        _check(_lib.mrs_swarm_set_mixer_params(self._h, first, count, C.byref(MixerParams(int(desaturation), 0))))
+
+    def set_rate_params(self, first, count, kp=4.0, kd=0.04, ki=0.0):
+        _check(_lib.mrs_swarm_set_rate_params(self._h, first, count, C.byref(RateParams(kp, kd, ki))))
+
+    def set_attitude_params(self, first, count, kp=6.0, kd=0.05, ki=0.01, max_rate_roll_pitch=10.0, max_rate_yaw=1.0):
+        _check(_lib.mrs_swarm_set_attitude_params(self._h, first, count,
+                                                  C.byref(AttitudeParams(kp, kd, ki, max_rate_roll_pitch, max_rate_yaw))))
+
+    def set_velocity_params(self, first, count, kp=2.0, kd=0.05, ki=0.01, max_acceleration=4.0):
+        _check(_lib.mrs_swarm_set_velocity_params(self._h, first, count, C.byref(VelocityParams(kp, kd, ki, max_acceleration))))
+
+    def set_position_params(self, first, count, kp=2.0, kd=0.15, ki=0.2, max_velocity=6.0):
+        _check(_lib.mrs_swarm_set_position_params(self._h, first, count, C.byref(PositionParams(kp, kd, ki, max_velocity))))
+
+    def get_mixer_allocation(self, uav):
+        out = np.zeros((self.get_params(uav).n_motors, 4))
+        _check(_lib.mrs_swarm_get_mixer_allocation(self._h, uav, _dp(out)))
+        return out
+
+    # -- commands --
+    def set_input(self, first, count, mode, payload=None):
+        if payload is None:
+            _check(_lib.mrs_swarm_set_input(self._h, first, count, mode, None, 0))
+            return
+        payload = _arr(payload).reshape(count, -1)
+        _check(_lib.mrs_swarm_set_input(self._h, first, count, mode, _dp(payload), payload.shape[1]))
+
+    def set_feedforward(self, first, count, kind, payload):
+        payload = _arr(payload).reshape(count, 4)
+        _check(_lib.mrs_swarm_set_feedforward(self._h, first, count, kind, _dp(payload), 4))
+
+    def apply_force(self, first, count, force):
+        _check(_lib.mrs_swarm_apply_force(self._h, first, count, _dp(_arr(force, (count, 3)))))
+
+    def crash(self, first, count):
+        _check(_lib.mrs_swarm_crash(self._h, first, count))
+
+    def has_crashed(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=np.int32)
+        _check(_lib.mrs_swarm_has_crashed(self._h, first, count, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    # -- hot path --
+    def step(self, dt):
+        _check(_lib.mrs_swarm_step(self._h, dt))
+
+    def step_n(self, dt, n_steps, substeps_per_launch=1):
+        _check(_lib.mrs_swarm_step_n(self._h, dt, n_steps, substeps_per_launch))
+
+    def handle_collisions(self, enabled, crash, rebounce):
+        _check(_lib.mrs_swarm_handle_collisions(self._h, int(enabled), int(crash), float(rebounce)))
+
+    def tick_n(self, dt, n_ticks, enabled, crash, rebounce):
+        _check(_lib.mrs_swarm_tick_n(self._h, dt, n_ticks, int(enabled), int(crash), float(rebounce)))
+
+    def synchronize(self):
+        _check(_lib.mrs_swarm_synchronize(self._h))
+
+    def stream(self):
+        st = C.c_void_p()
+        _check(_lib.mrs_swarm_stream(self._h, C.byref(st)))
+        return st.value
+
+    def set_profiling(self, enabled):
+        _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))
+
+    def last_step_kernel_ms(self):
+        ms, nl = C.c_double(), C.c_int32()
+        _check(_lib.mrs_swarm_last_step_kernel_ms(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    # -- multi-GPU collision exchange --
+    def pack_positions(self):
+        ptr, nb = C.c_void_p(), C.c_int64()
+        _check(_lib.mrs_swarm_pack_positions(self._h, C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
+    def handle_collisions_gathered(self, dev_ptr, n_total, my_offset, enabled, crash, rebounce):
+        _check(_lib.mrs_swarm_handle_collisions_gathered(self._h, C.c_void_p(dev_ptr), n_total, my_offset, int(enabled),
+                                                         int(crash), float(rebounce)))
+
+    # -- state --
+    def get_state(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        st = dict(x=np.zeros((count, 3)), v=np.zeros((count, 3)), v_prev=np.zeros((count, 3)), R=np.zeros((count, 3, 3)),
+                  omega=np.zeros((count, 3)), motor_rpm=np.zeros((count, MAX_MOTORS)))
+        _check(_lib.mrs_swarm_get_state(self._h, first, count, *[_dp(st[k]) for k in ("x", "v", "v_prev", "R", "omega", "motor_rpm")]))
+        return st
+
+    def set_state(self, first, count, x=None, v=None, R=None, omega=None, motor_rpm=None):
+        x, v, omega = _arr(x, (count, 3)), _arr(v, (count, 3)), _arr(omega, (count, 3))
+        R, motor_rpm = _arr(R, (count, 9)), _arr(motor_rpm, (count, MAX_MOTORS))
+        _check(_lib.mrs_swarm_set_state(self._h, first, count, _dp(x), _dp(v), _dp(R), _dp(omega), _dp(motor_rpm)))
+
+    def _get3(self, fn, first, count, width=3):
+        count = self.n - first if count is None else count
+        out = np.zeros((count, width))
+        _check(fn(self._h, first, count, _dp(out)))
+        return out
+
+    def get_imu(self, first=0, count=None):
+        return self._get3(_lib.mrs_swarm_get_imu, first, count)
+
+    def get_external_force(self, first=0, count=None):
+        return self._get3(_lib.mrs_swarm_get_external_force, first, count)
+
+    def get_pid(self, first=0, count=None):
+        return self._get3(_lib.mrs_swarm_get_pid, first, count, 24)
+
+    def get_diag(self):
+        d = Diag()
+        _check(_lib.mrs_swarm_get_diag(self._h, C.byref(d)))
+        return {k: int(getattr(d, k)) for k, _ in Diag._fields_}

@@ -1,0 +1,333 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via mrs_multirotor_simulator_amd.Swarm) against the
+CPU oracle on identical seeded inputs.  Tolerance of BASELINE.json's north_star: state L-inf <= 1e-6 relative (FP64);
+the LITERAL kernel is additionally held to 1e-11 (it repeats the reference's operation order without FMA contraction)."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import RTOL_FAST, RTOL_LITERAL, RTOL_NORTH_STAR, Pair, random_state
+
+pytestmark = pytest.mark.gpu
+DT = 0.001
+
+
+@pytest.fixture(scope="module")
+def M(mrs):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return mrs
+
+
+def goals(rng, n):
+    return np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(2, 20, (n, 1)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
+
+
+def payload_for(O, mode, rng, n, n_motors, st):
+    if mode == O.ACTUATOR_CMD:
+        return rng.uniform(0.35, 0.60, (n, n_motors))
+    if mode == O.CONTROL_GROUP_CMD:
+        return np.concatenate([rng.uniform(-0.1, 0.1, (n, 3)), rng.uniform(0.3, 0.7, (n, 1))], axis=1)
+    if mode == O.ATTITUDE_RATE_CMD:
+        return np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0.3, 0.7, (n, 1))], axis=1)
+    if mode == O.ATTITUDE_CMD:
+        Rd = helpers.tilted_rotations(rng, n, 0.4).reshape(n, 9)
+        return np.concatenate([Rd, rng.uniform(0.3, 0.7, (n, 1))], axis=1)
+    if mode == O.TILT_HDG_RATE_CMD:
+        tilt = helpers.tilted_rotations(rng, n, 0.4)[:, :, 2] * rng.uniform(0.5, 3.0, (n, 1))
+        return np.concatenate([tilt, rng.uniform(-1, 1, (n, 1)), rng.uniform(0.3, 0.7, (n, 1))], axis=1)
+    if mode in (O.ACCELERATION_HDG_RATE_CMD, O.ACCELERATION_HDG_CMD):
+        return np.concatenate([rng.uniform(-2, 2, (n, 3)), rng.uniform(-1, 1, (n, 1))], axis=1)
+    if mode in (O.VELOCITY_HDG_RATE_CMD, O.VELOCITY_HDG_CMD):
+        return np.concatenate([rng.uniform(-3, 3, (n, 3)), rng.uniform(-1, 1, (n, 1))], axis=1)
+    if mode == O.POSITION_CMD:
+        return np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_config3_actuator_single_step_random_states(M, oracle):
+    """BASELINE config 3 generator at an oracle-sized N: one step from random states, actuator references."""
+    rng = np.random.default_rng(3)
+    n = 4096
+    p = Pair(M, n)
+    p.construct(0, n, "x500")
+    p.set_state(0, n, random_state(rng, n, 4))
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, rng.uniform(0.35, 0.60, (n, 4)))
+    p.step(DT)
+    worst = p.compare(RTOL_LITERAL, "1 step")
+    p.step(DT, 100)
+    worst = max(worst, p.compare(RTOL_LITERAL, "101 steps"))
+    assert worst <= RTOL_NORTH_STAR
+
+
+@pytest.mark.parametrize("airframe", ["x500", "f550", "naki"])
+@pytest.mark.parametrize("mode", list(range(0, 11)))
+def test_every_input_mode(M, oracle, mode, airframe):
+    """All 11 INPUT_MODEs x {4,6,8} motors: 40 steps from random near-upright states."""
+    rng = np.random.default_rng(100 + mode)
+    n = 320  # five wavefronts
+    nm = M.AIRFRAMES[airframe]["n_motors"]
+    p = Pair(M, n)
+    p.construct(0, n, airframe)
+    st = random_state(rng, n, nm, tilted=True)
+    p.set_state(0, n, st)
+    p.both("set_input", 0, n, mode, payload_for(oracle, mode, rng, n, nm, st))
+    p.step(DT)
+    p.compare(RTOL_LITERAL, f"mode {mode} step 1")
+    p.step(DT, 39)
+    p.compare(RTOL_LITERAL, f"mode {mode} step 40")
+    assert p.g.get_diag() == p.o.get_diag()
+
+
+@pytest.mark.parametrize("mode,kinds", [(10, (1,)), (10, (0,)), (10, (0, 1, 2, 3)), (9, (3,)), (9, (2,)), (8, (2,)), (8, (3,)), (8, (2, 3))])
+def test_feedforward_slots(M, oracle, mode, kinds):
+    """std::optional feed-forwards and their priority order (uav_system.hpp:318-346)."""
+    rng = np.random.default_rng(7 + mode + sum(kinds))
+    n = 128
+    p = Pair(M, n)
+    p.construct(0, n, "x500")
+    st = random_state(rng, n, 4, tilted=True)
+    p.set_state(0, n, st)
+    for k in kinds:
+        p.both("set_feedforward", 0, n, k, rng.uniform(-1, 1, (n, 4)))
+    p.both("set_input", 0, n, mode, payload_for(oracle, mode, rng, n, 4, st))
+    p.step(DT, 25)
+    p.compare(RTOL_LITERAL, f"ff {kinds} mode {mode}")
+
+
+def test_config1_single_uav_trajectory(M, oracle):
+    """BASELINE config 1: 1 x500, spawn (10,15,0) hdg 3.14, two warm-up steps of 0.01 s, POSITION_CMD (12,13,5,1.0),
+    20 000 steps of 1 ms.  A swarm of one goes through the same kernel."""
+    p = Pair(M, 1)
+    p.construct(0, 1, "x500", pos=[[10, 15, 0]], heading=[3.14], ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
+    p.both("set_input", 0, 1, oracle.ACTUATOR_CMD, [[0.0] * 4])
+    p.step(0.01, 2)
+    p.compare(RTOL_LITERAL, "warm-up")
+    p.both("set_input", 0, 1, oracle.POSITION_CMD, [[12, 13, 5, 1.0]])
+    for k in range(20):
+        p.step(DT, 1000)
+        p.compare(RTOL_NORTH_STAR, f"step {1000 * (k + 1)}")
+    assert np.allclose(p.g.get_state()["x"][0], [11.997797, 13.003830, 4.995801], atol=2e-6)
+
+
+def test_config2_400_hexarotors(M, oracle):
+    """BASELINE config 2: 400 f550 on a 20x20 grid (4 m pitch), POSITION_CMD to goto.py-style goals, ground on."""
+    rng = np.random.default_rng(400)
+    n = 400
+    gx, gy = np.meshgrid(np.arange(20) * 4.0, np.arange(20) * 4.0, indexing="ij")
+    pos = np.stack([gx.ravel(), gy.ravel(), np.zeros(n)], axis=1)
+    p = Pair(M, n)
+    p.construct(0, n, "f550", pos=pos, heading=np.zeros(n), ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, np.zeros((n, 6)))
+    p.step(0.01, 2)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, goals(rng, n))
+    for k in range(4):
+        p.step(DT, 500)
+        p.compare(RTOL_NORTH_STAR, f"step {500 * (k + 1)}")
+
+
+def test_heterogeneous_swarm_and_ragged_tail(M, oracle):
+    """Mixed airframes inside one wavefront (type waterfall) and a swarm size that is not a multiple of 64."""
+    rng = np.random.default_rng(11)
+    n = 203
+    p = Pair(M, n)
+    names = ["x500", "f550", "naki", "t650", "a300"]
+    st_all = {}
+    for i in range(n):
+        af = names[i % len(names)] if i < 150 else "robofly"
+        p.construct(i, 1, af, pos=[rng.uniform(-50, 50, 3) + [0, 0, 100]], heading=[rng.uniform(-3, 3)])
+        nm = M.AIRFRAMES[af]["n_motors"]
+        st = random_state(rng, 1, nm, tilted=True)
+        p.set_state(i, 1, st)
+        st_all[i] = st
+        mode = [oracle.POSITION_CMD, oracle.ACTUATOR_CMD, oracle.VELOCITY_HDG_RATE_CMD, oracle.ATTITUDE_RATE_CMD][i % 4]
+        p.both("set_input", i, 1, mode, payload_for(oracle, mode, rng, 1, nm, st))
+    p.step(DT, 30)
+    p.compare(RTOL_LITERAL, "heterogeneous")
+
+
+def test_substep_fusion_is_bit_identical(M, oracle):
+    rng = np.random.default_rng(5)
+    n = 512
+    sw = [M.Swarm(n), M.Swarm(n)]
+    st = random_state(rng, n, 4, tilted=True)
+    g = goals(rng, n)
+    for s in sw:
+        s.construct(0, n, M.model_params("x500"))
+        s.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        s.set_input(0, n, M.POSITION_CMD, g)
+    sw[0].step_n(DT, 24, 1)
+    sw[1].step_n(DT, 24, 8)
+    a, b = sw[0].get_state(), sw[1].get_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(sw[0].get_pid(), sw[1].get_pid()) and np.array_equal(sw[0].get_imu(), sw[1].get_imu())
+
+
+def test_fast_arithmetic_within_tolerance(M, oracle):
+    rng = np.random.default_rng(9)
+    n = 2048
+    p = Pair(M, n, arith=M.ARITH_FAST)
+    p.construct(0, n, "x500")
+    st = random_state(rng, n, 4, tilted=True)
+    p.set_state(0, n, st)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, payload_for(oracle, oracle.POSITION_CMD, rng, n, 4, st))
+    p.step(DT)
+    p.compare(RTOL_FAST, "fast 1 step")
+    p.step(DT, 99)
+    p.compare(RTOL_NORTH_STAR, "fast 100 steps")
+
+
+def test_crash_force_ground_takeoff_and_nan_guards(M, oracle):
+    rng = np.random.default_rng(21)
+    n = 256
+    p = Pair(M, n)
+    p.construct(0, n, "x500", pos=np.concatenate([rng.uniform(-20, 20, (n, 2)), rng.uniform(0.0, 0.05, (n, 1))], axis=1),
+                heading=rng.uniform(-3, 3, n), ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=True)
+    thr = rng.uniform(0.0, 1.0, (n, 1)) * np.ones((1, 4))
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, thr)
+    p.both("crash", 10, 20)
+    p.both("apply_force", 40, 50, rng.normal(0, 5, (50, 3)))
+    p.step(DT, 300)  # some lift off (patch disabled), some stay clamped
+    p.compare(RTOL_LITERAL, "ground/takeoff")
+    assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
+    assert [p.g.get_params(i).takeoff_patch_enabled for i in range(n)] == [p.o.get_params(i).takeoff_patch_enabled for i in range(n)]
+    assert np.array_equal(p.g.get_external_force(), p.o.get_external_force())
+    # NaN guards: non-finite actuators -> 0; NaN throttle from an inverted attitude; NaN/inf state -> rollback
+    p.both("set_input", 0, 8, oracle.ACTUATOR_CMD, np.full((8, 4), np.nan))
+    p.both("set_input", 8, 8, oracle.ACTUATOR_CMD, np.full((8, 4), np.inf))
+    st = p.o.get_state(16, 8)
+    st["R"][:] = np.diag([1.0, -1.0, -1.0])
+    p.both("set_state", 16, 8, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    p.both("set_input", 16, 8, oracle.ACCELERATION_HDG_CMD, np.tile([0, 0, 0, 0.3], (8, 1)))
+    st = p.o.get_state(24, 4)
+    st["v"][:, 0] = [np.nan, np.inf, 1e200, -np.inf]
+    p.both("set_state", 24, 4, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    p.step(DT, 5)
+    p.compare(RTOL_LITERAL, "nan guards")
+    assert p.g.get_diag() == p.o.get_diag() and p.o.get_diag()["nan_rollback"] > 0
+
+
+def test_set_params_resets_controllers(M, oracle):
+    """set_mass semantics (src/uav_system_ros.cpp:1028-1053): new ModelParams -> default gains, fresh PIDs."""
+    rng = np.random.default_rng(33)
+    n = 64
+    p = Pair(M, n)
+    po = p.construct(0, n, "x500")
+    p.both("set_position_params", 0, n, 3.0, 0.2, 0.1, 5.0)
+    p.both("set_rate_params", 0, n, 5.0, 0.05, 0.01)
+    st = random_state(rng, n, 4, tilted=True)
+    p.set_state(0, n, st)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, payload_for(oracle, oracle.POSITION_CMD, rng, n, 4, st))
+    p.step(DT, 20)
+    p.compare(RTOL_LITERAL, "custom gains")
+    # mass change on half of the swarm, the way callbackSetMass does it
+    po2 = oracle.ModelParams.from_buffer_copy(bytes(po))
+    old = po2.mass
+    po2.mass = 2.6
+    for m in range(4):
+        po2.allocation_matrix[2 * 8 + m] = po2.mass * (po2.allocation_matrix[2 * 8 + m] / old)
+    oracle.lib().orc_calculate_inertia(po2)
+    p.o.set_params(0, n // 2, po2)
+    p.g.set_params(0, n // 2, helpers.to_product_params(M, po2))
+    assert np.all(p.g.get_pid(0, n // 2) == 0)
+    p.step(DT, 20)
+    p.compare(RTOL_LITERAL, "after set_params")
+    assert p.g.get_params(0).mass == 2.6 and p.g.get_params(n - 1).mass == 2.0
+
+
+@pytest.mark.parametrize("crash", [False, True])
+def test_collisions_match_oracle(M, oracle, crash):
+    """handleCollisions on a dense random cloud: forces / crash flags against the oracle, including the
+    squared-distance-vs-metres criterion and heterogeneous airframes."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    p = Pair(M, n)
+    pos = rng.uniform(0, 14, (n, 3))  # ~1 UAV per m^3: many pairs inside crit (~0.8 m^2)
+    p.construct(0, n // 2, "x500", pos=pos[: n // 2], heading=np.zeros(n // 2))
+    p.construct(n // 2, n - n // 2, "t650", pos=pos[n // 2:], heading=np.zeros(n - n // 2))
+    p.both("handle_collisions", True, crash, 100.0)
+    fo, fg = p.o.get_external_force(), p.g.get_external_force()
+    assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
+    if crash:
+        assert p.o.has_crashed().sum() > 100 and np.all(fg == 0)
+    else:
+        assert (np.abs(fo).sum(axis=1) > 0).sum() > 100
+        helpers.assert_close(fg, fo, 1e-14, "forces")
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, np.full((n, 4), 0.5))
+    p.step(DT, 3)
+    p.compare(RTOL_LITERAL, "step after collisions")
+    # disabled: early return leaves forces untouched (src/multirotor_simulator.cpp:299-301)
+    p.both("handle_collisions", False, False, 100.0)
+    assert np.array_equal(p.g.get_external_force(), fg)
+
+
+def test_collision_neighbour_set_vs_reference_kdtree(M, oracle):
+    """Pairs found by the GPU hash == pairs found by the reference's own nanoflann (oracle/_ref), via the force support."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    n = 5000
+    pos = rng.uniform(0, 30, (n, 3))
+    pos[:50] = pos[50:100] + rng.normal(0, 0.05, (50, 3))  # guaranteed close pairs
+    pos[100] = pos[101]  # coincident pair: normalized(0) = 0 -> zero force, still a neighbour
+    g = M.Swarm(n)
+    g.construct(0, n, M.model_params("x500"), pos, np.zeros(n))
+    g.handle_collisions(True, False, 100.0)
+    f = g.get_external_force()
+    off, idx, d2 = oracle.ref_radius_neighbours(pos, 3.0, 10)
+    crit = 2 * (0.25 + 0.15)
+    expect = np.zeros((n, 3))
+    for i in range(n):
+        js = idx[off[i]:off[i + 1]]
+        dd = d2[off[i]:off[i + 1]]
+        for j, d in sorted(zip(js, dd)):
+            if j != i and d < crit:
+                rel = pos[i] - pos[j]
+                nn = np.sqrt((rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2])
+                if nn > 0:
+                    rel = rel / nn
+                expect[i] += 100.0 * rel * 2.0 * (2.0 / (2.0 + 2.0))
+    assert (np.abs(expect).sum(axis=1) > 0).sum() >= 50
+    helpers.assert_close(f, expect, 1e-13, "forces vs reference kd-tree neighbours")
+
+
+def test_timer_main_tick_order(M, oracle):
+    """tick_n == {makeStep for all; handleCollisions} repeated (src/multirotor_simulator.cpp:211-217): forces act next tick."""
+    rng = np.random.default_rng(8)
+    n = 1500
+    p = Pair(M, n)
+    pos = rng.uniform(0, 12, (n, 3)) + [0, 0, 30]
+    p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n))
+    p.both("set_input", 0, n, oracle.POSITION_CMD, np.concatenate([pos + rng.uniform(-2, 2, (n, 3)), np.zeros((n, 1))], axis=1))
+    for _ in range(25):
+        p.o.step(DT)
+        p.o.handle_collisions(True, False, 100.0)
+    p.g.tick_n(DT, 25, True, False, 100.0)
+    p.compare(RTOL_LITERAL, "25 ticks with elastic collisions")
+    helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "forces")
+
+
+def test_full_size_100k_sample_against_oracle(M, oracle):
+    """BASELINE config 3 at its full size (100 000 UAVs): every UAV is independent, so a random sample of lanes
+    stepped alone by the oracle must agree with the same lanes inside the big launch (size-independence property)."""
+    rng = np.random.default_rng(3)
+    n = 100_000
+    g = M.Swarm(n)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True))
+    st = random_state(rng, n, 4)
+    cmd = rng.uniform(0.35, 0.60, (n, 4))
+    g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    g.set_input(0, n, M.ACTUATOR_CMD, cmd)
+    g.step_n(DT, 50)
+    pick = np.sort(rng.choice(n, 2000, replace=False))
+    pick[:3] = [0, 63, n - 1]
+    o = oracle.OracleSwarm(len(pick))
+    o.construct(0, len(pick), helpers.oracle_params("x500", ground_enabled=True))
+    o.set_state(0, len(pick), st["x"][pick], st["v"][pick], st["R"][pick], st["omega"][pick], st["motor_rpm"][pick])
+    o.set_input(0, len(pick), oracle.ACTUATOR_CMD, cmd[pick])
+    o.step_n(DT, 50)
+    a, b = g.get_state(), o.get_state()
+    for k in b:
+        helpers.assert_close(a[k][pick], b[k], RTOL_LITERAL, k)
+    assert np.all(np.isfinite(a["x"])) and np.allclose(np.einsum("nij,nik->njk", a["R"], a["R"]), np.eye(3), atol=1e-12)
