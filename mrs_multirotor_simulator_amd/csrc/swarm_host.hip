@@ -430,9 +430,11 @@ int mrs_model_params_default(mrs_model_params_t* p) {
 int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (!out || n_uavs < 0) return fail(MRS_ERR_ARG, "bad arguments");
   *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(MRS_ERR_HIP, "no HIP device available: libmrs_swarm has no CPU fallback");
+  int        ndev = 0;
+  hipError_t e0   = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev <= 0)
+    return fail(MRS_ERR_HIP, std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e0) + ", count " +
+                                 std::to_string(ndev) + "): libmrs_swarm has no CPU fallback");
   if (device_id < 0) HIPCHK(hipGetDevice(&device_id));
   if (device_id >= ndev) return fail(MRS_ERR_ARG, "device_id out of range");
   HIPCHK(hipSetDevice(device_id));

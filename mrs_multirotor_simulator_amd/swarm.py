@@ -71,6 +71,25 @@ ABI_SYMBOLS = [
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (RPATH $ORIGIN).  If
+    libmrs_swarm.so pulled in /opt/rocm's copy first and torch was imported later, two runtimes would coexist and
+    the second one sees no device.  So when torch is installed, its runtime is loaded first and libmrs_swarm.so
+    (same SONAME) binds to it; without torch the system ROCm runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library():
     """dlopen the in-tree libmrs_swarm.so (built by mrs_multirotor_simulator_amd.build / __graft_entry__.build)."""
     global _lib
@@ -79,6 +98,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise MrsError(f"{LIB_PATH} is missing: run `python -m mrs_multirotor_simulator_amd.build` "
                        "(the HIP extension is the only implementation; there is no CPU fallback)")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     i32, f64 = C.c_int32, C.c_double
