@@ -20,8 +20,8 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int substeps, hipStream_t st);
-extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int substeps, int cascade, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, int cascade, hipStream_t st);
 // collide.hip
 extern "C" hipError_t mrs_launch_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hipStream_t st);
@@ -219,6 +219,8 @@ struct mrs_swarm {
   std::vector<TypeParams> tparams;
   std::map<std::string, int> key_index;
   std::vector<uint16_t>   uav_type;
+  std::vector<uint8_t>    uav_mode;   // host mirror of active_input_: picks the kernel variant
+  int64_t n_cascade = 0;              // UAVs whose mode needs the controller cascade
   bool   types_dirty = true;
   double table_dt    = -1.0;
   // collision scratch
@@ -233,8 +235,23 @@ struct mrs_swarm {
   std::vector<double>   stage;  // host staging column
   std::vector<uint32_t> stage_u;
 
-  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, n, npad}; }
+  // per-64-block airframe type (0xFFFF = mixed) and the list of mixed blocks
+  std::vector<uint16_t> block_type;
+  std::vector<int32_t>  mixed_blocks;
+  uint16_t* dBT = nullptr;
+  int32_t*  dMB = nullptr;
+  bool      blocks_dirty = true;
+
+  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size()}; }
 };
+
+static void track_mode(mrs_swarm* s, int first, int count, int mode) {
+  for (int k = 0; k < count; k++) {
+    uint8_t& m = s->uav_mode[(size_t)first + k];
+    s->n_cascade += (mode >= MRS_CONTROL_GROUP_CMD) - (m >= MRS_CONTROL_GROUP_CMD);
+    m = (uint8_t)mode;
+  }
+}
 
 static int check_range(const mrs_swarm* s, int first, int count) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
@@ -275,7 +292,38 @@ static TypeKey make_key(const mrs_model_params_t* p) {
   return k;
 }
 
+static int upload_blocks(mrs_swarm* s) {
+  if (!s->blocks_dirty) return MRS_OK;
+  const int nb = s->npad / 64;
+  s->block_type.assign((size_t)nb, 0);
+  s->mixed_blocks.clear();
+  for (int b = 0; b < nb; b++) {
+    const int lo = b * 64, hi = (lo + 64 < s->n) ? lo + 64 : s->n;
+    uint16_t  t  = lo < s->n ? s->uav_type[(size_t)lo] : 0;
+    for (int i = lo + 1; i < hi; i++)
+      if (s->uav_type[(size_t)i] != t) {
+        t = 0xFFFFu;
+        break;
+      }
+    s->block_type[(size_t)b] = t;
+    if (t == 0xFFFFu) s->mixed_blocks.push_back(b);
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (!s->dBT) HIPCHK(hipMalloc(&s->dBT, sizeof(uint16_t) * (size_t)nb));
+  if (!s->dMB) HIPCHK(hipMalloc(&s->dMB, sizeof(int32_t) * (size_t)nb));
+  HIPCHK(hipMemcpyAsync(s->dBT, s->block_type.data(), sizeof(uint16_t) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
+  if (!s->mixed_blocks.empty())
+    HIPCHK(hipMemcpyAsync(s->dMB, s->mixed_blocks.data(), sizeof(int32_t) * s->mixed_blocks.size(), hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->blocks_dirty = false;
+  return MRS_OK;
+}
+
 static int upload_types(mrs_swarm* s, double dt) {
+  {
+    int rcb = upload_blocks(s);
+    if (rcb) return rcb;
+  }
   if (!s->types_dirty && dt == s->table_dt) return MRS_OK;
   if (dt != s->table_dt) {
     for (size_t i = 0; i < s->keys.size(); i++) {
@@ -358,6 +406,7 @@ static int set_controller_params(mrs_swarm* s, int first, int count, int pid_fie
         nt = it->second;
       }
       s->uav_type[(size_t)first + k] = (uint16_t)nt;
+      s->blocks_dirty = true;
     }
     if (k == count || nt != run_type) {
       if (run_type >= 0 && (rc = flags_update(s, run_start, first + k - run_start, ~(0xFFFFu << FLAG_TYPE_SHIFT), (uint32_t)run_type << FLAG_TYPE_SHIFT)))
@@ -451,6 +500,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   HIPCHK(hipMemsetAsync(s->dF, 0, sizeof(uint32_t) * (size_t)s->npad, s->stream));
   HIPCHK(hipMemsetAsync(s->dDiag, 0, sizeof(unsigned long long) * 4, s->stream));
   s->uav_type.assign((size_t)s->npad, 0);
+  s->uav_mode.assign((size_t)s->npad, (uint8_t)MRS_INPUT_UNKNOWN);
   *out = s;
   if (n_uavs > 0) {
     int rc = mrs_swarm_construct(s, 0, n_uavs, nullptr, nullptr, nullptr);
@@ -467,6 +517,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   mrs_collide_free(s->cwork);
   if (s->dRec) (void)hipFree(s->dRec);
   if (s->dT) (void)hipFree(s->dT);
+  if (s->dBT) (void)hipFree(s->dBT);
+  if (s->dMB) (void)hipFree(s->dMB);
   (void)hipFree(s->dDiag);
   (void)hipFree(s->dF);
   (void)hipFree(s->dS);
@@ -509,7 +561,8 @@ int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_
   TypeKey key = make_key(params);
   int     type;
   if ((rc = intern_type(s, key, &type))) return rc;
-  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type;
+  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type, s->blocks_dirty = true;
+  track_mode(s, first, count, MRS_INPUT_UNKNOWN);
   // MultirotorModel::initializeState (multirotor_model.hpp:183-198): everything zero, R = I
   for (int f = 0; f < F_COUNT; f++) {
     const bool diag = (f == F_R + 0 || f == F_R + 4 || f == F_R + 8);
@@ -538,7 +591,7 @@ int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs
   TypeKey key = make_key(params);  // default gains: initializeControllers(), uav_system.hpp:404-409
   int     type;
   if ((rc = intern_type(s, key, &type))) return rc;
-  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type;
+  for (int k = 0; k < count; k++) s->uav_type[(size_t)first + k] = (uint16_t)type, s->blocks_dirty = true;
   for (int f = F_PID; f < F_PID + 24; f++)
     if ((rc = fill_column(s, f, first, count, 0.0))) return rc;
   return flags_update(s, first, count, ~((0xFFFFu << FLAG_TYPE_SHIFT) | FLAG_TAKEOFF),
@@ -611,6 +664,7 @@ int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mo
   }
   for (int j = 0; j < width; j++)
     if ((rc = put_strided(s, F_CMD + j, first, count, payload, stride, j))) return rc;
+  track_mode(s, first, count, mode);
   return flags_update(s, first, count, ~FLAG_MODE_MASK, (uint32_t)mode << FLAG_MODE_SHIFT);
 }
 
@@ -670,10 +724,11 @@ static int launch_step(mrs_swarm* s, double dt, int substeps) {
     s->ev_used += 2;
     HIPCHK(hipEventRecord(e0, s->stream));
   }
+  const int cascade = s->n_cascade > 0;
   if (s->arith == MRS_ARITH_FAST)
-    HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, s->stream));
+    HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, cascade, s->stream));
   else
-    HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, s->stream));
+    HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, cascade, s->stream));
   if (s->profiling) HIPCHK(hipEventRecord(e1, s->stream));
   return MRS_OK;
 }

@@ -64,7 +64,9 @@ struct SwarmDev {
   uint32_t*           F;      // npad
   const TypeParams*   T;      // type table
   unsigned long long* diag;   // 4 counters (mrs_diag_t order)
-  int32_t             n, npad;
+  const uint16_t*     BT;     // airframe type of each 64-UAV block, 0xFFFF when the block mixes types
+  const int32_t*      MB;     // indices of the mixed blocks (n_mixed entries)
+  int32_t             n, npad, n_mixed;
 };
 
 // 48-byte record exchanged for the collision pass (single- and multi-GPU): everything

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmrs_swarm.so")
+# MRS_SWARM_LIB: alternative build of the same library (kernel tuning sweeps, tools/tune_step.py)
+LIB_PATH = os.environ.get("MRS_SWARM_LIB") or os.path.join(HERE, "libmrs_swarm.so")
 MAX_MOTORS = 8
 
 (INPUT_UNKNOWN, ACTUATOR_CMD, CONTROL_GROUP_CMD, ATTITUDE_RATE_CMD, ATTITUDE_CMD, TILT_HDG_RATE_CMD,
