@@ -28,6 +28,19 @@ BYTES_PER_UAV_STEP = {
 }
 
 
+def pmc_traffic(args, n):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC summary of this same command (profiles/), corrected as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950 (confirmed by the calibration rows of that summary for this
+    8-B/lane SoA pattern), WRITE_SIZE exact, both x1024.  None when no summary matches the configuration."""
+    path = os.path.join(ROOT, "profiles", f"r01_step_kernel_{n // 1000}k_{args.arith}_summary.json")
+    if args.workload != "actuator" or args.substeps != 1 or not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path)).get("pmc", {})
+    if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
+        return None, None
+    return (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,7 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--uavs", type=int, default=100_000, help="UAVs per GPU")
     ap.add_argument("--workload", choices=["actuator", "position", "position+collisions"], default="actuator")
-    ap.add_argument("--arith", choices=["literal", "fast"], default="literal")
+    ap.add_argument("--arith", choices=["literal", "fast"], default="fast",
+                    help="fast: FMA + rsqrt arithmetic (within 1e-6 of the reference, the production flavour); literal: reference op order")
     ap.add_argument("--substeps", type=int, default=1, help="makeStep rounds fused per launch (state kept in registers)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,21 +141,17 @@ def main():
 
     run(args.warmup)
     barrier()
+    sw.set_profiling(1)  # one hipEvent pair around the timed region, recorded on the swarm's stream
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
+    kern_ms, n_launch = sw.last_step_kernel_ms()
+    sw.set_profiling(0)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-
-    # second pass of the same K steps with a hipEvent pair around every step-kernel launch on the swarm's stream
-    sw.set_profiling(True)
-    run(args.steps)
-    sw.synchronize()
-    kern_ms, n_launch = sw.last_step_kernel_ms()
-    sw.set_profiling(False)
 
     assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
     if rank == 0:
@@ -149,6 +159,7 @@ def main():
         per_launch_steps = args.substeps if not coll else 1
         alg_bytes = BYTES_PER_UAV_STEP[key] * n * per_launch_steps
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args, n)
         out = {
             "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -158,9 +169,9 @@ def main():
                        "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
                        "parallelism": f"{world} independent shard(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": f"mrs_uav_step_{args.arith}", "kernel_avg_ms": kern_ms, "launches": n_launch,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": ("mrs_uav_model_step_" if args.workload == "actuator" else "mrs_uav_step_") + args.arith, "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
-                         "method": "hipEvent pair around each launch on the swarm's stream, second pass of the same K steps"},
+                         "method": "one hipEvent pair around the timed region on the swarm's stream: elapsed / launches (inter-launch gaps included)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, st, cmd)

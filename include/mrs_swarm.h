@@ -168,10 +168,11 @@ int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes);
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,
                                          int32_t enabled, int32_t crash, double rebounce);
 
-/* last launch timing helper: average device time (ms) of the step kernel launches issued by the last
- * mrs_swarm_step_n / mrs_swarm_tick_n call, measured with hipEvents on the swarm's stream */
+/* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
+ * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
+ * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */
 int mrs_swarm_last_step_kernel_ms(mrs_swarm_t* s, double* avg_ms, int32_t* n_launches);
-int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled);
+int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t mode);
 
 #ifdef __cplusplus
 }

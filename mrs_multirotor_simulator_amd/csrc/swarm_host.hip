@@ -227,18 +227,19 @@ struct mrs_swarm {
   PosRecord*   dRec = nullptr;
   CollideWork* cwork = nullptr;
   // profiling
-  bool profiling = false;
+  int  profiling = 0;  // 0 off, 1 one event pair around the whole step_n/tick_n region, 2 one pair per step launch
   std::vector<hipEvent_t> ev;
   int  ev_used = 0;
+  int  region_launches = 0;
   double last_ms = 0.0;
   int    last_launches = 0;
   std::vector<double>   stage;  // host staging column
   std::vector<uint32_t> stage_u;
 
   // per-64-block airframe type (0xFFFF = mixed) and the list of mixed blocks
-  std::vector<uint16_t> block_type;
+  std::vector<uint32_t> block_type;
   std::vector<int32_t>  mixed_blocks;
-  uint16_t* dBT = nullptr;
+  uint32_t* dBT = nullptr;
   int32_t*  dMB = nullptr;
   bool      blocks_dirty = true;
 
@@ -305,13 +306,13 @@ static int upload_blocks(mrs_swarm* s) {
         t = 0xFFFFu;
         break;
       }
-    s->block_type[(size_t)b] = t;
+    s->block_type[(size_t)b] = (uint32_t)t | ((t == 0xFFFFu ? (uint32_t)MRS_MAX_MOTORS : (uint32_t)s->keys[t].mp.n_motors) << 16);
     if (t == 0xFFFFu) s->mixed_blocks.push_back(b);
   }
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (!s->dBT) HIPCHK(hipMalloc(&s->dBT, sizeof(uint16_t) * (size_t)nb));
+  if (!s->dBT) HIPCHK(hipMalloc(&s->dBT, sizeof(uint32_t) * (size_t)nb));
   if (!s->dMB) HIPCHK(hipMalloc(&s->dMB, sizeof(int32_t) * (size_t)nb));
-  HIPCHK(hipMemcpyAsync(s->dBT, s->block_type.data(), sizeof(uint16_t) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipMemcpyAsync(s->dBT, s->block_type.data(), sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice, s->stream));
   if (!s->mixed_blocks.empty())
     HIPCHK(hipMemcpyAsync(s->dMB, s->mixed_blocks.data(), sizeof(int32_t) * s->mixed_blocks.size(), hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -713,7 +714,8 @@ int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t*
 // ---- hot path ----
 static int launch_step(mrs_swarm* s, double dt, int substeps) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (s->profiling) {
+  s->region_launches++;
+  if (s->profiling == 2) {
     while ((int)s->ev.size() < s->ev_used + 2) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -729,11 +731,34 @@ static int launch_step(mrs_swarm* s, double dt, int substeps) {
     HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, cascade, s->stream));
   else
     HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, cascade, s->stream));
-  if (s->profiling) HIPCHK(hipEventRecord(e1, s->stream));
+  if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
+  return MRS_OK;
+}
+
+static int begin_profile(mrs_swarm* s) {
+  s->ev_used          = 0;
+  s->region_launches  = 0;
+  if (s->profiling == 1) {
+    while (s->ev.size() < 2) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      s->ev.push_back(e);
+    }
+    HIPCHK(hipEventRecord(s->ev[0], s->stream));
+  }
   return MRS_OK;
 }
 
 static int finish_profile(mrs_swarm* s) {
+  if (s->profiling == 1) {
+    HIPCHK(hipEventRecord(s->ev[1], s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    s->last_launches = s->region_launches;
+    s->last_ms       = s->region_launches ? (double)ms / s->region_launches : 0.0;
+    return MRS_OK;
+  }
   if (!s->profiling || s->ev_used == 0) return MRS_OK;
   HIPCHK(hipStreamSynchronize(s->stream));
   double total = 0;
@@ -755,7 +780,7 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, dt);
   if (rc) return rc;
-  s->ev_used = 0;
+  if ((rc = begin_profile(s))) return rc;
   int left = n_steps;
   while (left > 0) {
     const int sub = left < substeps_per_launch ? left : substeps_per_launch;
@@ -806,7 +831,7 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, dt);
   if (rc) return rc;
-  s->ev_used = 0;
+  if ((rc = begin_profile(s))) return rc;
   for (int k = 0; k < n_ticks; k++) {
     if ((rc = launch_step(s, dt, 1))) return rc;
     if ((rc = mrs_swarm_handle_collisions(s, enabled, crash, rebounce))) return rc;
@@ -888,7 +913,7 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
 
 int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
-  s->profiling = enabled != 0;
+  s->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return MRS_OK;
 }
 

@@ -64,7 +64,7 @@ struct SwarmDev {
   uint32_t*           F;      // npad
   const TypeParams*   T;      // type table
   unsigned long long* diag;   // 4 counters (mrs_diag_t order)
-  const uint16_t*     BT;     // airframe type of each 64-UAV block, 0xFFFF when the block mixes types
+  const uint32_t*     BT;     // per 64-UAV block: airframe type (0xFFFF = mixed types) | n_motors << 16
   const int32_t*      MB;     // indices of the mixed blocks (n_mixed entries)
   int32_t             n, npad, n_mixed;
 };
