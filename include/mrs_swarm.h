@@ -163,6 +163,8 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out);
 /* device pointer + byte size of this shard's packed {x,y,z,mass,arm_length,prop_radius} records (48 B/UAV), refreshed by
  * mrs_swarm_pack_positions; the caller all-gathers them (RCCL) into a buffer of n_total records */
 int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes);
+/* same records written to caller-owned device memory (e.g. the send buffer of an RCCL all-gather): n_uavs x 48 B */
+int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst);
 /* handleCollisions for this shard against ALL gathered records (device pointer, n_total x 48 B);
  * my_offset = index of this shard's first UAV in the gathered order */
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,

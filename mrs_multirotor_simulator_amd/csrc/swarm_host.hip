@@ -804,6 +804,15 @@ int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
   return MRS_OK;
 }
 
+int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst) {
+  if (!s || !dev_dst) return fail(MRS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
+  if (rc) return rc;
+  HIPCHK(mrs_launch_pack_positions(s->view(), (PosRecord*)dev_dst, s->stream));
+  return MRS_OK;
+}
+
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset, int32_t enabled,
                                          int32_t crash, double rebounce) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_set_input", "mrs_swarm_set_feedforward", "mrs_swarm_apply_force", "mrs_swarm_crash",
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
-    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_pack_positions", "mrs_swarm_handle_collisions_gathered",
+    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -138,6 +138,7 @@ def load_library():
         "mrs_swarm_get_pid": [vp, i32, i32, dp],
         "mrs_swarm_get_diag": [vp, C.POINTER(Diag)],
         "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
+        "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
@@ -291,6 +292,9 @@ class Swarm:
         ptr, nb = C.c_void_p(), C.c_int64()
         _check(_lib.mrs_swarm_pack_positions(self._h, C.byref(ptr), C.byref(nb)))
         return ptr.value, nb.value
+
+    def pack_positions_to(self, dev_ptr):
+        _check(_lib.mrs_swarm_pack_positions_to(self._h, C.c_void_p(dev_ptr)))
 
     def handle_collisions_gathered(self, dev_ptr, n_total, my_offset, enabled, crash, rebounce):
         _check(_lib.mrs_swarm_handle_collisions_gathered(self._h, C.c_void_p(dev_ptr), n_total, my_offset, int(enabled),

@@ -331,3 +331,102 @@ def test_full_size_100k_sample_against_oracle(M, oracle):
     for k in b:
         helpers.assert_close(a[k][pick], b[k], RTOL_LITERAL, k)
     assert np.all(np.isfinite(a["x"])) and np.allclose(np.einsum("nij,nik->njk", a["R"], a["R"]), np.eye(3), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# FAST arithmetic (the production flavour bench.py measures): same scenarios, north-star tolerance
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("airframe", ["x500", "f550", "naki"])
+@pytest.mark.parametrize("mode", list(range(0, 11)))
+def test_every_input_mode_fast_arithmetic(M, oracle, mode, airframe):
+    rng = np.random.default_rng(100 + mode)
+    n = 192
+    nm = M.AIRFRAMES[airframe]["n_motors"]
+    p = Pair(M, n, arith=M.ARITH_FAST)
+    p.construct(0, n, airframe)
+    st = random_state(rng, n, nm, tilted=True)
+    p.set_state(0, n, st)
+    p.both("set_input", 0, n, mode, payload_for(oracle, mode, rng, n, nm, st))
+    p.step(DT)
+    p.compare(RTOL_FAST, f"fast mode {mode} step 1")
+    p.step(DT, 39)
+    p.compare(RTOL_NORTH_STAR, f"fast mode {mode} step 40")
+
+
+def test_config3_fast_arithmetic_1000_steps(M, oracle):
+    """the bench workload itself (config 3 generator), 1000 steps, FAST kernel vs oracle at the north-star tolerance."""
+    rng = np.random.default_rng(3)
+    n = 2048
+    p = Pair(M, n, arith=M.ARITH_FAST)
+    p.construct(0, n, "x500", ground_enabled=True)
+    p.set_state(0, n, random_state(rng, n, 4))
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, rng.uniform(0.35, 0.60, (n, 4)))
+    p.step(DT, 1000)
+    p.compare(RTOL_NORTH_STAR, "config 3, 1000 steps, fast")
+
+
+def test_config2_fast_arithmetic(M, oracle):
+    rng = np.random.default_rng(400)
+    n = 400
+    gx, gy = np.meshgrid(np.arange(20) * 4.0, np.arange(20) * 4.0, indexing="ij")
+    pos = np.stack([gx.ravel(), gy.ravel(), np.zeros(n)], axis=1)
+    p = Pair(M, n, arith=M.ARITH_FAST)
+    p.construct(0, n, "f550", pos=pos, heading=np.zeros(n), ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, np.zeros((n, 6)))
+    p.step(0.01, 2)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, goals(rng, n))
+    p.step(DT, 2000)
+    p.compare(RTOL_NORTH_STAR, "config 2, 2000 steps, fast")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU collision exchange, exercised on one GPU
+# ------------------------------------------------------------------------------------------------------------------
+def test_gathered_collisions_from_two_virtual_shards(M, oracle):
+    """Two shards (two Swarm objects on this GPU) pack their 48-B records, the records are concatenated with NaN padding the
+    way ShardedSwarm's all-gather lays them out, and each shard collides against the gathered buffer with its offset."""
+    import torch
+    from mrs_multirotor_simulator_amd.sharded import max_shard, shard_range
+    rng = np.random.default_rng(99)
+    n_total, world = 2001, 2
+    pos = rng.uniform(0, 13, (n_total, 3))
+    o = oracle.OracleSwarm(n_total)
+    po = helpers.oracle_params("x500")
+    pt = helpers.oracle_params("t650")
+    half = shard_range(n_total, world, 0)[1]
+    o.construct(0, half, po, pos[:half], np.zeros(half))
+    o.construct(half, n_total - half, pt, pos[half:], np.zeros(n_total - half))
+    o.handle_collisions(True, False, 100.0)
+    n_max = max_shard(n_total, world)
+    recv = torch.full((world * n_max, 6), float("nan"), dtype=torch.float64, device="cuda")
+    shards = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, world, r)
+        g = M.Swarm(hi - lo)
+        g.construct(0, hi - lo, helpers.to_product_params(M, po if r == 0 else pt), pos[lo:hi], np.zeros(hi - lo))
+        g.pack_positions_to(recv[r * n_max:].data_ptr())
+        g.synchronize()
+        shards.append((g, lo, hi))
+    torch.cuda.synchronize()
+    for r, (g, lo, hi) in enumerate(shards):
+        g.handle_collisions_gathered(recv.data_ptr(), world * n_max, r * n_max, True, False, 100.0)
+        helpers.assert_close(g.get_external_force(), o.get_external_force(lo, hi - lo), 1e-13, f"shard {r} forces")
+    assert (np.abs(o.get_external_force()).sum(axis=1) > 0).sum() > 100
+
+
+def test_sharded_swarm_world1_on_gpu(M, oracle):
+    import torch
+    from mrs_multirotor_simulator_amd.sharded import GpuEngine, ShardedSwarm
+    rng = np.random.default_rng(17)
+    n = 1000
+    pos = rng.uniform(0, 10, (n, 3)) + [0, 0, 20]
+    p = Pair(M, n)
+    p.construct(0, n, "x500", pos=pos, heading=np.zeros(n))
+    cmd = np.concatenate([pos + rng.uniform(-2, 2, (n, 3)), np.zeros((n, 1))], axis=1)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, cmd)
+    sh = ShardedSwarm(n, GpuEngine(p.g, torch.device("cuda", 0)), torch.device("cuda", 0))
+    sh.tick_n(DT, 10, True, False, 100.0)
+    for _ in range(10):
+        p.o.step(DT)
+        p.o.handle_collisions(True, False, 100.0)
+    p.compare(RTOL_LITERAL, "sharded world=1")

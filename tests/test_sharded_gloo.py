@@ -1,0 +1,111 @@
+"""world_size-2 `gloo` tests (CPU) of the multi-GPU collision exchange: shard ranges, padded all-gather layout, and that
+shard-local collision results equal the single-process result.  The local engine here is the CPU oracle (test
+infrastructure) behind the same three calls the GPU engine implements."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def test_shard_ranges_cover_everything():
+    from mrs_multirotor_simulator_amd.sharded import max_shard, shard_range
+    for n in (0, 1, 7, 64, 1000, 100_003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == (max_shard(n, w) if n else 0)
+
+
+class OracleEngine:
+    """Each rank keeps a full oracle replica but OWNS only [lo, hi): foreign positions arrive through the all-gather."""
+
+    def __init__(self, O, sw, lo, hi, n_total, world, n_max):
+        self.O, self.sw, self.lo, self.hi, self.n_total, self.world, self.n_max = O, sw, lo, hi, n_total, world, n_max
+
+    def step(self, dt):
+        self.sw.step(dt)
+
+    def write_records(self, out):
+        st = self.sw.get_state(self.lo, self.hi - self.lo)
+        rec = np.zeros((self.hi - self.lo, 6))
+        rec[:, :3] = st["x"]
+        for k in range(self.hi - self.lo):
+            p = self.sw.get_params(self.lo + k)
+            rec[k, 3:] = (p.mass, p.arm_length, p.prop_radius)
+        out.copy_(torch.from_numpy(rec))
+
+    def collide(self, records, n_records, my_offset, enabled, crash, rebounce):
+        from mrs_multirotor_simulator_amd.sharded import shard_range
+        rec = records.numpy()
+        assert n_records == self.world * self.n_max and my_offset == dist.get_rank() * self.n_max
+        # install the gathered foreign positions into the replica, then run the reference semantics on all UAVs
+        for r in range(self.world):
+            lo, hi = shard_range(self.n_total, self.world, r)
+            blk = rec[r * self.n_max: r * self.n_max + (hi - lo)]
+            assert np.all(np.isnan(rec[r * self.n_max + (hi - lo): (r + 1) * self.n_max]))  # padding
+            if r != dist.get_rank() and hi > lo:
+                st = self.sw.get_state(lo, hi - lo)
+                self.sw.set_state(lo, hi - lo, blk[:, :3].copy(), st["v"], st["R"], st["omega"], st["motor_rpm"])
+        self.sw.handle_collisions(enabled, crash, rebounce)
+
+
+def _worker(rank, world, port, n_total, result_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers
+    from mrs_multirotor_simulator_amd.sharded import ShardedSwarm, max_shard, shard_range
+    from oracle import oracle_swarm as O
+    rng = np.random.default_rng(1234)  # same scenario on every rank
+    pos = rng.uniform(0, 9, (n_total, 3)) + [0, 0, 20]
+    goal = np.concatenate([pos + rng.uniform(-2, 2, (n_total, 3)), np.zeros((n_total, 1))], axis=1)
+    po = helpers.oracle_params("x500")
+    sw = O.OracleSwarm(n_total)
+    sw.construct(0, n_total, po, pos, np.zeros(n_total))
+    sw.set_input(0, n_total, O.POSITION_CMD, goal)
+    lo, hi = shard_range(n_total, world, rank)
+    eng = OracleEngine(O, sw, lo, hi, n_total, world, max_shard(n_total, world))
+    sh = ShardedSwarm(n_total, eng, torch.device("cpu"))
+    assert (sh.lo, sh.hi) == (lo, hi)
+    assert [sh.global_index(k) for k in (0, sh.n_max - 1, sh.n_max)] == [0, (sh.n_max - 1 if sh.n_max - 1 < shard_range(n_total, world, 0)[1] else -1), shard_range(n_total, world, 1)[0]]
+    sh.tick_n(0.001, 12, True, False, 100.0)
+    st = sw.get_state(lo, hi - lo)
+    np.savez(os.path.join(result_dir, f"rank{rank}.npz"), x=st["x"], v=st["v"], f=sw.get_external_force(lo, hi - lo), lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [257, 300])
+def test_sharded_ticks_match_single_process(tmp_path, oracle, n_total):
+    import helpers
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + n_total % 7
+    mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    O = oracle
+    rng = np.random.default_rng(1234)
+    pos = rng.uniform(0, 9, (n_total, 3)) + [0, 0, 20]
+    goal = np.concatenate([pos + rng.uniform(-2, 2, (n_total, 3)), np.zeros((n_total, 1))], axis=1)
+    ref = O.OracleSwarm(n_total)
+    ref.construct(0, n_total, helpers.oracle_params("x500"), pos, np.zeros(n_total))
+    ref.set_input(0, n_total, O.POSITION_CMD, goal)
+    for _ in range(12):
+        ref.step(0.001)
+        ref.handle_collisions(True, False, 100.0)
+    st, f = ref.get_state(), ref.get_external_force()
+    assert (np.abs(f).sum(axis=1) > 0).sum() > 10  # the scenario really collides
+    covered = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        lo, hi = int(d["lo"]), int(d["hi"])
+        covered += hi - lo
+        assert np.array_equal(d["x"], st["x"][lo:hi]) and np.array_equal(d["v"], st["v"][lo:hi]) and np.array_equal(d["f"], f[lo:hi])
+    assert covered == n_total
