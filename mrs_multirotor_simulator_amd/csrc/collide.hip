@@ -15,9 +15,12 @@
 //   pack      : SoA state + type table -> 48-B PosRecord per UAV            (also the multi-GPU all-gather payload)
 //   hash_count: cell = floor(pos / 1.75 m) (> sqrt(3), so partners sit in the 27 adjacent cells);
 //               bucket = hash(cell) & (T-1); rank = atomicAdd(count[bucket])
-//   scan      : exclusive prefix sum of count[T] (three small kernels)
-//   scatter   : sorted[start[bucket] + rank] = j ; each bucket then ordered by index (deterministic)
-//   query     : one lane per local UAV walks the 27 buckets, exact cell match (dedupes shared buckets), literal predicate
+//   alloc     : every 1024-bucket block scans its counts and reserves its slice of `sorted` with one atomicAdd
+//               (buckets need disjoint slices, not ordered ones); writes {start,count} per bucket, re-zeroes count[]
+//   scatter   : sorted[start[bucket] + rank] = j
+//   query     : one lane per local UAV fetches the 27 bucket descriptors, walks the non-empty ones with an exact cell
+//               match (dedupes buckets shared by several cells) and the literal predicate; partners are consumed in
+//               ascending index, which makes the result independent of the atomic arrival order
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,7 +28,8 @@
 
 namespace {
 
-constexpr double CELL_EDGE = 1.75;       // > sqrt(3.0) = 1.7320508
+constexpr double INV_CELL  = 1.0 / 1.75; // cell edge 1.75 m > sqrt(3.0) = 1.7320508; // cells are floor(pos * INV_CELL): any consistent assignment with edge > sqrt(3) works,
+                                         // and the multiply avoids three ~70-cycle IEEE divisions per cell_of
 constexpr double POS_LIMIT = 1.0e9;      // |coordinate| beyond this (or non-finite) never collides here
 
 struct Cell { int x, y, z; bool ok; };
@@ -33,14 +37,20 @@ struct Cell { int x, y, z; bool ok; };
 __device__ __forceinline__ Cell cell_of(double x, double y, double z) {
   Cell c;
   c.ok = (fabs(x) < POS_LIMIT) && (fabs(y) < POS_LIMIT) && (fabs(z) < POS_LIMIT);  // false for NaN/inf
-  c.x  = c.ok ? (int)floor(x / CELL_EDGE) : 0;
-  c.y  = c.ok ? (int)floor(y / CELL_EDGE) : 0;
-  c.z  = c.ok ? (int)floor(z / CELL_EDGE) : 0;
+  c.x  = c.ok ? (int)floor(x * INV_CELL) : 0;
+  c.y  = c.ok ? (int)floor(y * INV_CELL) : 0;
+  c.z  = c.ok ? (int)floor(z * INV_CELL) : 0;
   return c;
 }
 
+// the column (cx, cy) is hashed, cz is added: the three z-neighbours of a cell sit in consecutive buckets, so a UAV's 27
+// probes touch ~9 cache lines of the descriptor table instead of 27
 __device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t mask) {
-  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u)) & mask;
+  uint32_t h = ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return (h + (uint32_t)cz) & mask;
 }
 
 __global__ void k_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask) {
@@ -75,7 +85,10 @@ __global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t m
   rank[j] = atomicAdd(&count[b], 1u);
 }
 
-// ---- exclusive scan over T = nblocks * 1024 counters ----
+// ---- bucket storage allocation: one kernel instead of a full prefix sum ----
+// Buckets need disjoint slices of `sorted`, not slices in bucket order: each 1024-bucket block scans its own counts
+// in registers/LDS and reserves its total with ONE atomicAdd on a global cursor.  Writes {start, count} per bucket and
+// re-zeroes count[] for the next tick (this kernel is its last reader).
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total) {
   __shared__ uint32_t wsum[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -90,133 +103,238 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* to
   uint32_t base = 0;
   for (int q = 0; q < wv; q++) base += wsum[q];
   *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  __syncthreads();
   return base + inc - v;
 }
 
-__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t* count, uint32_t* bsum) {
-  const uint4 c = reinterpret_cast<const uint4*>(count)[(size_t)blockIdx.x * 256 + threadIdx.x];
-  uint32_t    total;
-  block_excl_scan_256(c.x + c.y + c.z + c.w, &total);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(256) k_scan_top(uint32_t* bsum, int nblocks) {  // one workgroup
-  uint32_t carry = 0;
-  for (int base = 0; base < nblocks; base += 256) {
-    const int      idx = base + threadIdx.x;
-    const uint32_t v   = idx < nblocks ? bsum[idx] : 0u;
-    uint32_t       total;
-    const uint32_t ex = block_excl_scan_256(v, &total);
-    if (idx < nblocks) bsum[idx] = carry + ex;
-    carry += total;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_scan_finish(const uint32_t* count, const uint32_t* bsum, uint32_t* start) {
+__global__ void __launch_bounds__(256) k_alloc_buckets(uint32_t* count, uint2* cell, uint32_t* cursor) {
+  __shared__ uint32_t block_base;
   const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
   const uint4  c = reinterpret_cast<const uint4*>(count)[q];
   uint32_t     total;
-  const uint32_t ex = block_excl_scan_256(c.x + c.y + c.z + c.w, &total) + bsum[blockIdx.x];
-  uint4 o;
-  o.x = ex;
-  o.y = ex + c.x;
-  o.z = o.y + c.y;
-  o.w = o.z + c.z;
-  reinterpret_cast<uint4*>(start)[q] = o;
+  const uint32_t ex = block_excl_scan_256(c.x + c.y + c.z + c.w, &total);
+  if (threadIdx.x == 0) block_base = total ? atomicAdd(cursor, total) : 0u;
+  __syncthreads();
+  const uint32_t s0 = block_base + ex;
+  uint2* o = cell + q * 4;
+  o[0] = make_uint2(s0, c.x);
+  o[1] = make_uint2(s0 + c.x, c.y);
+  o[2] = make_uint2(s0 + c.x + c.y, c.z);
+  o[3] = make_uint2(s0 + c.x + c.y + c.z, c.w);
+  reinterpret_cast<uint4*>(count)[q] = make_uint4(0, 0, 0, 0);
 }
 
-__global__ void k_scatter(long long n_total, const uint32_t* key, const uint32_t* rank, const uint32_t* start, uint32_t* sorted) {
+__global__ void k_scatter(long long n_total, const uint32_t* key, const uint32_t* rank, const uint2* cell, uint32_t* sorted) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_total) return;
   const uint32_t b = key[j];
   if (b == 0xFFFFFFFFu) return;
-  sorted[start[b] + rank[j]] = (uint32_t)j;
+  sorted[cell[b].x + rank[j]] = (uint32_t)j;  // (scattering the 48-B records as well was measured 6x slower than this kernel)
 }
 
-// order every bucket by UAV index so that the force sums do not depend on atomic arrival order
-__global__ void k_sort_buckets(uint32_t T, const uint32_t* count, const uint32_t* start, uint32_t* sorted) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= T) return;
-  const uint32_t c = count[b];
-  if (c < 2) return;
-  uint32_t* p = sorted + start[b];
-  for (uint32_t a = 1; a < c; a++) {
-    const uint32_t val = p[a];
-    uint32_t       q   = a;
-    while (q > 0 && p[q - 1] > val) {
-      p[q] = p[q - 1];
-      q--;
+// ---- query ----
+// accumulate one partner into the force / crash state of a UAV (literal predicate and force expression)
+__device__ __forceinline__ void apply_partner(const PosRecord& me, const PosRecord& o, int crash, double rebounce, double& fx, double& fy,
+                                              double& fz, bool& crashed) {
+  const double d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
+  const double dist    = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
+  const double crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
+  const double crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
+  if (crash) {
+    // the reference crashes the partner of every qualifying ordered pair (i -> idx); seen from the partner's side:
+    // this UAV is crashed iff some j has it as a qualifying partner, i.e. dist < crit(j, i)
+    if (dist < crit_ji) crashed = true;
+  } else if (dist < crit_ij) {
+    double r0 = d0, r1 = d1, r2 = d2;
+    const double z = (r0 * r0 + r1 * r1) + r2 * r2;  // Eigen normalized()
+    if (z > 0) {
+      const double nn = sqrt(z);
+      r0 /= nn; r1 /= nn; r2 /= nn;
     }
-    p[q] = val;
+    const double ratio = o.mass / (me.mass + o.mass);
+    fx += ((rebounce * r0) * me.mass) * ratio;
+    fy += ((rebounce * r1) * me.mass) * ratio;
+    fz += ((rebounce * r2) * me.mass) * ratio;
   }
 }
 
-// one lane per local UAV.  Partners are consumed in ascending global index: each round finds the smallest hit
-// index above the previous one (no per-lane arrays; >= 1 partner is rare, so normally a single sweep).
-__global__ void __launch_bounds__(256) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
-                                               const uint32_t* count, const uint32_t* start, const uint32_t* sorted, int crash,
-                                               double rebounce) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sw.n) return;
-  const long long gi = my_offset + i;
-  const PosRecord me = rec[gi];
-  const Cell      c  = cell_of(me.x, me.y, me.z);
+__device__ __forceinline__ bool qualifies(const PosRecord& me, const PosRecord& o, int crash) {
+  const double d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
+  const double dist = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
+  if (!(dist < 3.0)) return false;  // nanoflann RadiusResultSet(3.0) on the squared distance
+  const double crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
+  const double crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
+  return dist < crit_ij || (crash && dist < crit_ji);
+}
+
+// reference path for one lane: repeated sweeps over the 27 buckets, each returning the smallest qualifying partner
+// index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
+// occupancy; used when the wave-cooperative path below overflows its LDS lists.
+__device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask,
+                                  const uint2* cell, const uint32_t* sorted, int crash, double rebounce, double& fx, double& fy, double& fz,
+                                  bool& crashed) {
+  long long prev = -1;
+  for (;;) {
+    long long best = n_total;
+    for (int q = 0; q < 27; q++) {
+      const int   cx = c.x + q / 9 - 1, cy = c.y + (q / 3) % 3 - 1, cz = c.z + q % 3 - 1;
+      const uint2 info = cell[bucket_of(cx, cy, cz, mask)];
+      for (uint32_t e = 0; e < info.y; e++) {
+        const long long j = sorted[info.x + e];
+        if (j <= prev || j >= best || j == gi) continue;
+        const PosRecord o  = rec[j];
+        const Cell      oc = cell_of(o.x, o.y, o.z);
+        if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // another cell sharing the bucket
+        if (qualifies(me, o, crash)) best = j;
+      }
+    }
+    if (best >= n_total) break;
+    apply_partner(me, rec[best], crash, rebounce, fx, fy, fz, crashed);
+    prev = best;
+  }
+}
+
+// Wave-cooperative query, one single-wave workgroup per 64 local UAVs.
+//   A  every lane fetches its 27 bucket descriptors and the first entry of each non-empty bucket (independent loads,
+//      one memory round trip), and counts its candidates (~2 on a 64 m^3/UAV swarm: nearly all buckets are empty)
+//   B  the (owner lane, candidate) pairs of the whole wave are compacted into an LDS list (wave prefix sum)
+//   C  the list is processed 64 pairs at a time with uniform control flow — this is what removes the 27-way divergent
+//      walk in which some lane always had a non-empty bucket and every iteration paid a full memory latency;
+//      qualifying partners go to a small per-owner hit list (LDS atomics)
+//   D  owners order their (rare) hits by index and accumulate; overflow of either list falls back to query_lane_sweeps
+constexpr int PAIR_CAP = 1024;
+constexpr int HIT_CAP  = 6;
+
+__global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
+                                              const uint2* cell, const uint32_t* sorted, int crash, double rebounce) {
+  __shared__ PosRecord me_s[64];
+  __shared__ int4      me_cell[64];
+  __shared__ uint32_t  pair_j[PAIR_CAP];
+  __shared__ uint8_t   pair_owner[PAIR_CAP];
+  __shared__ int8_t    pair_q[PAIR_CAP];
+  __shared__ uint32_t  hit_j[64][HIT_CAP];
+  __shared__ uint32_t  hit_n[64];
+  __shared__ uint32_t  wave_total, overflow;
+
+  const int       lane   = threadIdx.x;
+  const int       i      = blockIdx.x * 64 + lane;
+  const bool      active = i < sw.n;
+  const long long gi     = my_offset + i;
+  PosRecord       me;
+  me.x = me.y = me.z = __longlong_as_double(0x7ff8000000000000ll);
+  me.mass = me.arm_length = me.prop_radius = 0.0;
+  if (active) me = rec[gi];
+  const Cell c = cell_of(me.x, me.y, me.z);
+  me_s[lane]   = me;
+  me_cell[lane] = make_int4(c.x, c.y, c.z, 0);
+  hit_n[lane]  = 0;
+  if (lane == 0) overflow = 0;
+
+  // A: descriptors and candidate count.  Unconditional loads from always-valid addresses: a load under a divergent
+  // branch is waited for at the join, which would serialise 27 memory round trips.
+  uint2    info[27];
+  uint32_t tc = 0;
+#pragma unroll
+  for (int q = 0; q < 27; q++) info[q] = cell[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
+#pragma unroll
+  for (int q = 0; q < 27; q++) {
+    if (!c.ok) info[q] = make_uint2(0u, 0u);
+    tc += info[q].y;
+  }
+  // B: wave prefix sum -> slots in the pair list; a pair is (owner lane, probed cell q, position in `sorted`)
+  uint32_t inc = tc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wave_total = inc;
+  __syncthreads();
+  const uint32_t total = wave_total;
+  if (total > PAIR_CAP) {  // wave-uniform: dense neighbourhood, take the reference path
+    double fx = 0, fy = 0, fz = 0;
+    bool   crashed = false;
+    if (active && c.ok) query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, crash, rebounce, fx, fy, fz, crashed);
+    if (active) {
+      sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
+      sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
+      sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
+      if (crashed) sw.F[i] |= FLAG_CRASHED;
+    }
+    return;
+  }
+  uint32_t slot = inc - tc;
+#pragma unroll
+  for (int q = 0; q < 27; q++) {
+    const uint32_t cn = info[q].y;
+    for (uint32_t e = 0; e < cn; e++) {  // LDS writes only
+      pair_j[slot]     = info[q].x + e;
+      pair_owner[slot] = (uint8_t)lane;
+      pair_q[slot]     = (int8_t)q;
+      slot++;
+    }
+  }
+  __syncthreads();
+  // C: uniform sweep over the pairs, four independent pairs per lane and iteration so that their loads overlap
+  constexpr int U = 4;
+  for (uint32_t base = 0; base < total; base += 64 * U) {
+    uint32_t  pos[U], jj[U];
+    PosRecord o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t p = base + u * 64 + lane;
+      pos[u] = (p < total) ? pair_j[p] : pair_j[0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) jj[u] = sorted[pos[u]];
+#pragma unroll
+    for (int u = 0; u < U; u++) o[u] = rec[jj[u]];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t p = base + u * 64 + lane;
+      if (p >= total) continue;
+      const int  ow = pair_owner[p], q = pair_q[p];
+      const int4 mc = me_cell[ow];
+      if ((long long)jj[u] == my_offset + blockIdx.x * 64 + ow) continue;  // idx == i, src/multirotor_simulator.cpp:335
+      const Cell oc = cell_of(o[u].x, o[u].y, o[u].z);
+      if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // other cell, same bucket
+      const PosRecord m = me_s[ow];
+      if (!qualifies(m, o[u], crash)) continue;
+      const uint32_t k = atomicAdd(&hit_n[ow], 1u);
+      if (k < HIT_CAP)
+        hit_j[ow][k] = jj[u];
+      else
+        overflow = 1;
+    }
+  }
+  __syncthreads();
+  // D: owners accumulate their hits in ascending partner index
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
-  if (c.ok) {
-    long long prev = -1;
-    for (;;) {
-      long long best = n_total;  // smallest qualifying partner index > prev
-      for (int dx = -1; dx <= 1; dx++)
-        for (int dy = -1; dy <= 1; dy++)
-          for (int dz = -1; dz <= 1; dz++) {
-            const int      cx = c.x + dx, cy = c.y + dy, cz = c.z + dz;
-            const uint32_t b  = bucket_of(cx, cy, cz, mask);
-            const uint32_t s0 = start[b], cn = count[b];
-            for (uint32_t e = 0; e < cn; e++) {
-              const long long j = sorted[s0 + e];
-              if (j <= prev || j >= best || j == gi) continue;  // buckets are index-ordered but cells interleave
-              const PosRecord o  = rec[j];
-              const Cell      oc = cell_of(o.x, o.y, o.z);
-              if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // other cell sharing the bucket
-              const double d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
-              const double dist = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
-              if (!(dist < 3.0)) continue;
-              const double crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
-              const double crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
-              if (dist < crit_ij || (crash && dist < crit_ji)) best = j;
-            }
-          }
-      if (best >= n_total) break;
-      const PosRecord o  = rec[best];
-      const double    d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
-      const double    dist    = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
-      const double    crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
-      const double    crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
-      if (crash) {
-        // the reference crashes the partner of every qualifying ordered pair (i -> idx); seen from the partner's
-        // side: this UAV is crashed iff some j has it as a qualifying partner, i.e. dist < crit(j, i)
-        if (dist < crit_ji) crashed = true;
-      } else if (dist < crit_ij) {
-        double r0 = d0, r1 = d1, r2 = d2;
-        const double z = (r0 * r0 + r1 * r1) + r2 * r2;  // Eigen normalized()
-        if (z > 0) {
-          const double nn = sqrt(z);
-          r0 /= nn; r1 /= nn; r2 /= nn;
+  if (active && c.ok) {
+    if (overflow && hit_n[lane] > HIT_CAP) {
+      query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, crash, rebounce, fx, fy, fz, crashed);
+    } else {
+      const uint32_t nh = hit_n[lane];
+      uint32_t       prev = 0;
+      bool           have_prev = false;
+      for (uint32_t r = 0; r < nh; r++) {  // selection by repeated minimum: nh <= 6, almost always 0 or 1
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < nh; k++) {
+          const uint32_t j = hit_j[lane][k];
+          if ((!have_prev || j > prev) && j < best) best = j;
         }
-        const double ratio = o.mass / (me.mass + o.mass);
-        fx += ((rebounce * r0) * me.mass) * ratio;
-        fy += ((rebounce * r1) * me.mass) * ratio;
-        fz += ((rebounce * r2) * me.mass) * ratio;
+        apply_partner(me, rec[best], crash, rebounce, fx, fy, fz, crashed);
+        prev = best;
+        have_prev = true;
       }
-      prev = best;
     }
   }
-  sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
-  sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
-  sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
-  if (crashed) sw.F[i] |= FLAG_CRASHED;
+  if (active) {
+    sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
+    sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
+    sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
+    if (crashed) sw.F[i] |= FLAG_CRASHED;
+  }
 }
 
 }  // namespace
@@ -224,12 +342,18 @@ __global__ void __launch_bounds__(256) k_query(SwarmDev sw, const PosRecord* rec
 struct CollideWork {
   long long cap_n = 0;
   uint32_t  cap_T = 0;
-  uint32_t *key = nullptr, *rank = nullptr, *sorted = nullptr, *count = nullptr, *start = nullptr, *bsum = nullptr;
+  uint32_t *key = nullptr, *rank = nullptr, *sorted = nullptr, *count = nullptr, *cursor = nullptr;
+  uint2*    cell = nullptr;
 };
+
+static void free_work(CollideWork* w) {
+  (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->cursor);
+  (void)hipFree(w->cell);
+}
 
 extern "C" void mrs_collide_free(CollideWork* w) {
   if (!w) return;
-  (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->start); (void)hipFree(w->bsum);
+  free_work(w);
   delete w;
 }
 
@@ -255,30 +379,28 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
   uint32_t     T = 1024;
-  while ((long long)T < 2 * n_total) T <<= 1;
+  while ((long long)T < 4 * n_total) T <<= 1;  // load factor <= 0.25: ~27*0.25 false candidates per UAV
   if (n_total > w->cap_n || T > w->cap_T) {
     CK(hipStreamSynchronize(st));
-    (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->start); (void)hipFree(w->bsum);
+    free_work(w);
     CK(hipMalloc(&w->key, sizeof(uint32_t) * (size_t)n_total));
     CK(hipMalloc(&w->rank, sizeof(uint32_t) * (size_t)n_total));
     CK(hipMalloc(&w->sorted, sizeof(uint32_t) * (size_t)n_total));
     CK(hipMalloc(&w->count, sizeof(uint32_t) * (size_t)T));
-    CK(hipMalloc(&w->start, sizeof(uint32_t) * (size_t)T));
-    CK(hipMalloc(&w->bsum, sizeof(uint32_t) * (size_t)(T / 1024)));
+    CK(hipMalloc(&w->cell, sizeof(uint2) * (size_t)T));
+    CK(hipMalloc(&w->cursor, sizeof(uint32_t)));
+    CK(hipMemsetAsync(w->count, 0, sizeof(uint32_t) * (size_t)T, st));  // k_alloc_buckets re-zeroes it after every use
     w->cap_n = n_total;
     w->cap_T = T;
   }
-  const uint32_t mask    = T - 1;
-  const int      nblocks = (int)(T / 1024);
-  const unsigned gN      = (unsigned)((n_total + 255) / 256);
-  CK(hipMemsetAsync(w->count, 0, sizeof(uint32_t) * (size_t)T, st));
+  T = w->cap_T;  // a larger table from an earlier call is still valid (count[] is all zero between ticks)
+  const uint32_t mask = T - 1;
+  const unsigned gN   = (unsigned)((n_total + 255) / 256);
+  CK(hipMemsetAsync(w->cursor, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->count);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, w->count, w->bsum);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, w->bsum, nblocks);
-  hipLaunchKernelGGL(k_scan_finish, dim3(nblocks), dim3(256), 0, st, w->count, w->bsum, w->start);
-  hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->start, w->sorted);
-  hipLaunchKernelGGL(k_sort_buckets, dim3(T / 256), dim3(256), 0, st, T, w->count, w->start, w->sorted);
-  hipLaunchKernelGGL(k_query, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, rec, n_total, my_offset, mask, w->count, w->start,
-                     w->sorted, crash, rebounce);
+  hipLaunchKernelGGL(k_alloc_buckets, dim3(T / 1024), dim3(256), 0, st, w->count, w->cell, w->cursor);
+  hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->cell, w->sorted);
+  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, w->cell, w->sorted, crash,
+                     rebounce);
   return hipGetLastError();
 }
