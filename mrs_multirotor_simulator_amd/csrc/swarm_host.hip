@@ -161,6 +161,8 @@ static void derive_type(const TypeKey& k, double dt, TypeParams& t) {
   t.hover_thr      = 0.90 * sqrt((p.mass * p.g) / (p.n_motors * p.kf));
   t.ground_z       = p.ground_z;
   t.tau            = p.motor_time_constant;
+  t.inv_kf_n       = 1.0 / t.kf_n;
+  t.inv_rpm_range  = 1.0 / (p.max_rpm - p.min_rpm);
   t.filt_c         = exp((-dt) / (p.motor_time_constant));
   t.filt_1mc       = 1.0 - t.filt_c;
   t.arm_length     = p.arm_length;
@@ -243,7 +245,9 @@ struct mrs_swarm {
   int32_t*  dMB = nullptr;
   bool      blocks_dirty = true;
 
-  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size()}; }
+  bool      fext_active = false;  // apply_force / collisions were used at least once
+
+  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size(), fext_active ? 1u : 0u}; }
 };
 
 static void track_mode(mrs_swarm* s, int first, int count, int mode) {
@@ -688,6 +692,7 @@ int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const do
   HIPCHK(hipSetDevice(s->device));
   for (int j = 0; j < 3; j++)
     if ((rc = put_strided(s, F_FEXT + j, first, count, force, 3, j))) return rc;
+  s->fext_active = true;
   return MRS_OK;
 }
 
@@ -726,11 +731,11 @@ static int launch_step(mrs_swarm* s, double dt, int substeps) {
     s->ev_used += 2;
     HIPCHK(hipEventRecord(e0, s->stream));
   }
-  const int cascade = s->n_cascade > 0;
+  const int variant = s->n_cascade > 0 ? 0 : 1;  // 0 all input modes | 1 model only
   if (s->arith == MRS_ARITH_FAST)
-    HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, cascade, s->stream));
+    HIPCHK(mrs_launch_step_fast(s->view(), dt, substeps, variant, s->stream));
   else
-    HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, cascade, s->stream));
+    HIPCHK(mrs_launch_step_literal(s->view(), dt, substeps, variant, s->stream));
   if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
   return MRS_OK;
 }
@@ -820,6 +825,7 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
   if (!dev_records || n_total < s->n || my_offset < 0 || my_offset + s->n > n_total) return fail(MRS_ERR_ARG, "bad gathered-record arguments");
   if (s->n == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
+  s->fext_active = true;
   HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, s->stream));
   return MRS_OK;
 }
@@ -860,6 +866,17 @@ int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x,
     if (it.p)
       for (int j = 0; j < it.w; j++)
         if ((rc = get_strided(s, it.f + j, first, count, it.p, it.w, j))) return rc;
+  if (v_prev) {  // v_prev == v unless the UAV is flagged (see FLAG_VPREV_SPLIT)
+    std::vector<uint32_t> fl((size_t)count);
+    std::vector<double>   vv((size_t)count * 3);
+    HIPCHK(hipMemcpyAsync(fl.data(), s->dF + first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int j = 0; j < 3; j++)
+      if ((rc = get_strided(s, F_V + j, first, count, vv.data(), 3, j))) return rc;
+    for (int k = 0; k < count; k++)
+      if (!(fl[(size_t)k] & FLAG_VPREV_SPLIT))
+        for (int j = 0; j < 3; j++) v_prev[(size_t)k * 3 + j] = vv[(size_t)k * 3 + j];
+  }
   return MRS_OK;
 }
 
@@ -870,6 +887,23 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
   if (count == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   struct { const double* p; int f, w; } items[5] = {{x, F_X, 3}, {v, F_V, 3}, {R, F_R, 9}, {omega, F_W, 3}, {motor_rpm, F_RPM, MRS_MAX_MOTORS}};
+  if (v) {
+    // MultirotorModel::setState leaves v_prev alone: materialise it in its column (it equals the old v unless the flag is
+    // already set) before v is overwritten, and mark the UAVs
+    std::vector<uint32_t> fl((size_t)count);
+    HIPCHK(hipMemcpyAsync(fl.data(), s->dF + first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    std::vector<double> oldv((size_t)count), vp((size_t)count);
+    for (int j = 0; j < 3; j++) {
+      HIPCHK(hipMemcpyAsync(oldv.data(), s->dS + (size_t)(F_V + j) * s->npad + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipMemcpyAsync(vp.data(), s->dS + (size_t)(F_VPREV + j) * s->npad + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      for (int k = 0; k < count; k++)
+        if (!(fl[(size_t)k] & FLAG_VPREV_SPLIT)) vp[(size_t)k] = oldv[(size_t)k];
+      if ((rc = put_column(s, F_VPREV + j, first, count, vp.data()))) return rc;
+    }
+    if ((rc = flags_update(s, first, count, ~0u, FLAG_VPREV_SPLIT))) return rc;
+  }
   for (auto& it : items)
     if (it.p)
       for (int j = 0; j < it.w; j++)

@@ -33,6 +33,9 @@ enum {
 #define FLAG_MODE_MASK (0xFu << FLAG_MODE_SHIFT)
 #define FLAG_FF_SHIFT  6           // 4 bits: which std::optional feed-forwards hold a value
 #define FLAG_FF_MASK   (0xFu << FLAG_FF_SHIFT)
+#define FLAG_VPREV_SPLIT 0x400u   // v_prev differs from v: the F_VPREV column is authoritative.  After every step v_prev == v
+                                  // (multirotor_model.hpp:281), so the step kernel neither reads nor writes F_VPREV unless
+                                  // MultirotorModel::setState changed v in between (:424-433 leaves v_prev alone)
 #define FLAG_TYPE_SHIFT 16         // 16 bits: index into the type table
 #define MRS_MAX_TYPES  65536
 
@@ -48,6 +51,7 @@ struct TypeParams {
   double  filt_c;     // exp(-dt/motor_time_constant) for the dt of the current launch   :244
   double  filt_1mc;   // 1.0 - filt_c
   double  tau;        // motor_time_constant
+  double  inv_kf_n, inv_rpm_range;  // FAST flavour: 1/(kf*n_motors), 1/(max_rpm-min_rpm)
   double  arm_length, prop_radius;  // collision criterion             src/multirotor_simulator.cpp:342
   double  J[9], Jinv[9];            // Jinv = Eigen 3x3 cofactor inverse of J     multirotor_model.hpp:350
   double  alloc[4 * MRS_MAXM];      // torque/thrust allocation, row-major 4 x 8  :334
@@ -67,6 +71,7 @@ struct SwarmDev {
   const uint32_t*     BT;     // per 64-UAV block: airframe type (0xFFFF = mixed types) | n_motors << 16
   const int32_t*      MB;     // indices of the mixed blocks (n_mixed entries)
   int32_t             n, npad, n_mixed;
+  uint32_t            opts;   // bit 0: some UAV may carry a non-zero external force (else the F_FEXT columns are not read)
 };
 
 // 48-byte record exchanged for the collision pass (single- and multi-GPU): everything

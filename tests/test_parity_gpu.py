@@ -430,3 +430,28 @@ def test_sharded_swarm_world1_on_gpu(M, oracle):
         p.o.step(DT)
         p.o.handle_collisions(True, False, 100.0)
     p.compare(RTOL_LITERAL, "sharded world=1")
+
+
+def test_set_state_keeps_v_prev_like_the_reference(M, oracle):
+    """MultirotorModel::setState (multirotor_model.hpp:424-433) overwrites v but not v_prev; the step kernel normally
+    elides the v_prev column (v_prev == v after every step), so this is the one path where the column matters."""
+    rng = np.random.default_rng(123)
+    n = 200
+    p = Pair(M, n)
+    p.construct(0, n, "x500")
+    p.set_state(0, n, random_state(rng, n, 4))
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, rng.uniform(0.35, 0.6, (n, 4)))
+    p.compare(RTOL_LITERAL, "after first set_state (v_prev = 0)")
+    p.step(DT, 3)
+    p.compare(RTOL_LITERAL, "stepped")
+    assert np.array_equal(p.g.get_state()["v_prev"], p.g.get_state()["v"])
+    st2 = random_state(rng, 50, 4)
+    p.set_state(40, 50, st2)       # v replaced on a sub-range, v_prev must stay the pre-set_state velocity
+    p.compare(RTOL_LITERAL, "after second set_state")
+    p.set_state(60, 10, random_state(rng, 10, 4))  # twice in a row: v_prev still the value from before the first one
+    p.compare(RTOL_LITERAL, "after third set_state")
+    p.step(DT)
+    p.compare(RTOL_LITERAL, "IMU uses the kept v_prev")
+    p.both("apply_force", 0, 20, rng.normal(0, 3, (20, 3)))  # first force ever applied to this swarm
+    p.step(DT, 2)
+    p.compare(RTOL_LITERAL, "external force switched on")

@@ -14,14 +14,7 @@ OBJ = os.path.join(ROOT, "mrs_multirotor_simulator_amd", "build")
 VARIANTS = {
     "default": "",
     "w1": "-DMRS_WAVES_PER_SIMD=1",
-    "w1_unrolled": "-DMRS_WAVES_PER_SIMD=1 -DMRS_ROLL_STAGES=0",
-    "w2_sb": "-DMRS_SCHED_BARRIER=1",
-    "w2_pre": "-DMRS_PRELOAD=1",
-    "w1_pre": "-DMRS_PRELOAD=1 -DMRS_WAVES_PER_SIMD=1",
-    "w1_unr_pre": "-DMRS_PRELOAD=1 -DMRS_WAVES_PER_SIMD=1 -DMRS_ROLL_STAGES=0",
-    "w3_sb": "-DMRS_SCHED_BARRIER=1 -DMRS_WAVES_PER_SIMD=3",
-    "w2_lds": "-DMRS_LDS_STAGE=1",
-    "w2_lds_sb": "-DMRS_LDS_STAGE=1 -DMRS_SCHED_BARRIER=1",
+    "w3": "-DMRS_WAVES_PER_SIMD=3",
 }
 
 
