@@ -97,8 +97,17 @@ def cpu_baseline(args, st, cmd):
         el = time.perf_counter() - t0
         if el > args.cpu_seconds:
             break
-    return {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c -O2 -ffp-contract=off, 1 thread"}
+    out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c -O2 -ffp-contract=off, 1 thread "
+                     "(the reference's loop is serial, src/multirotor_simulator.cpp:211-213)"}
+    if not coll:  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
+        cores = os.cpu_count() or 1
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < max(3.0, args.cpu_seconds / 3):
+            o.step_n(DT, 10, cores)
+            k += 10
+        out["all_cores"] = {"value": n * k / (time.perf_counter() - t0), "cores": cores}
+    return out
 
 
 def main():
@@ -125,8 +134,16 @@ def main():
     sw.set_input(0, n, M.ACTUATOR_CMD if args.workload == "actuator" else M.POSITION_CMD, cmd)
     coll = args.workload.endswith("collisions")
 
+    sharded = None
+    if coll and world > 1:  # BASELINE configs[4]: index shards + ONE all-gather of 48-B records per tick (RCCL over xGMI)
+        from mrs_multirotor_simulator_amd.sharded import GpuEngine, ShardedSwarm
+        dev = torch.device("cuda", local)
+        sharded = ShardedSwarm(n * world, GpuEngine(sw, dev), dev)
+
     def run(k):
-        if coll:
+        if sharded is not None:
+            sharded.tick_n(DT, k, True, False, 100.0)
+        elif coll:
             sw.tick_n(DT, k, True, False, 100.0)
         else:
             sw.step_n(DT, k, args.substeps)
@@ -141,12 +158,12 @@ def main():
 
     run(args.warmup)
     barrier()
-    sw.set_profiling(1)  # one hipEvent pair around the timed region, recorded on the swarm's stream
+    sw.set_profiling(0 if sharded is not None else 1)  # one hipEvent pair around the timed region, on the swarm's stream
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    kern_ms, n_launch = sw.last_step_kernel_ms()
+    kern_ms, n_launch = sw.last_step_kernel_ms() if sharded is None else (el / args.steps * 1e3, args.steps)
     sw.set_profiling(0)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
@@ -167,7 +184,8 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {args.workload} references, dt=1 ms, RK4, ground on"
                        if args.workload == "actuator" else f"{n} x500 UAVs per GPU, {args.workload}, dt=1 ms",
                        "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
-                       "parallelism": f"{world} independent shard(s), no collective"},
+                       "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and world > 1)
+                                       else f"{world} independent shard(s), no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": ("mrs_uav_model_step_" if args.workload == "actuator" else "mrs_uav_step_") + args.arith, "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],

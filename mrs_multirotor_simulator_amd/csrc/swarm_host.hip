@@ -906,8 +906,16 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
   }
   for (auto& it : items)
     if (it.p)
-      for (int j = 0; j < it.w; j++)
-        if ((rc = put_strided(s, it.f + j, first, count, it.p, it.w, j))) return rc;
+      for (int j = 0; j < it.w; j++) {
+        if (it.f == F_RPM) {  // state_.motor_rpm has n_motors entries: columns beyond a UAV's motor count stay zero
+          s->stage.resize((size_t)count);
+          for (int k = 0; k < count; k++)
+            s->stage[(size_t)k] = j < s->keys[s->uav_type[(size_t)first + k]].mp.n_motors ? it.p[(size_t)k * it.w + j] : 0.0;
+          if ((rc = put_column(s, it.f + j, first, count, s->stage.data()))) return rc;
+        } else if ((rc = put_strided(s, it.f + j, first, count, it.p, it.w, j))) {
+          return rc;
+        }
+      }
   return MRS_OK;
 }
 

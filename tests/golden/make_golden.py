@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures of tests/golden/ (run in the build container, where /root/reference is mounted).
+
+* nanoflann_radius_sets.npz — OUTPUT OF THE REFERENCE'S OWN CODE: include/nanoflann.hpp +
+  KDTreeVectorOfVectorsAdaptor.h compiled unmodified (oracle/Makefile -> oracle/_ref) and queried exactly like
+  src/multirotor_simulator.cpp:309-328 (3 dims, leaf_max_size 10, RadiusResultSet(3.0)) on seeded point clouds.
+  Inputs (points) and outputs (CSR neighbour lists with squared distances) are stored.
+* oracle_trajectories.npz — regression vectors of the CPU oracle (NOT reference outputs: the reference's dynamics cannot be
+  built here) for BASELINE config 1 and a 64-UAV mixed-mode swarm; they freeze the oracle so that a later
+  edit of oracle/uav_oracle.c cannot silently move the parity target.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+from oracle import oracle_swarm as O  # noqa: E402
+
+
+def nanoflann_sets():
+    assert O.ref_lib() is not None, "oracle/_ref must be built from /root/reference"
+    rng = np.random.default_rng(2025)
+    clouds = {
+        "dense": rng.uniform(0, 10, (600, 3)),
+        "sparse": rng.uniform(-100, 100, (800, 3)),
+        "grid12": np.stack(np.meshgrid(np.arange(12) * 1.2, np.arange(12) * 1.2, [0.0, 1.2], indexing="ij"), -1).reshape(-1, 3),
+        "tmux400": np.stack(np.meshgrid(np.arange(20) * 4.0, np.arange(20) * 4.0, [0.0], indexing="ij"), -1).reshape(-1, 3),
+    }
+    out = {}
+    for name, pts in clouds.items():
+        off, idx, d2 = O.ref_radius_neighbours(pts, 3.0, 10)
+        # canonical order inside a query (the kd-tree's traversal order is an implementation detail)
+        for i in range(len(pts)):
+            o = np.argsort(idx[off[i]:off[i + 1]], kind="stable")
+            idx[off[i]:off[i + 1]] = idx[off[i]:off[i + 1]][o]
+            d2[off[i]:off[i + 1]] = d2[off[i]:off[i + 1]][o]
+        out[f"{name}_points"], out[f"{name}_offsets"], out[f"{name}_indices"], out[f"{name}_d2"] = pts, off, idx, d2
+    np.savez_compressed(os.path.join(HERE, "nanoflann_radius_sets.npz"), **out)
+
+
+def oracle_trajectories():
+    out = {}
+    p = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
+    s = O.OracleSwarm(1)
+    s.construct(0, 1, p, [[10, 15, 0]], [3.14])
+    for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+        getattr(s, nm)(0, 1)
+    s.set_input(0, 1, O.ACTUATOR_CMD, [[0.0] * 4])
+    s.step_n(0.01, 2)
+    s.set_input(0, 1, O.POSITION_CMD, [[12, 13, 5, 1.0]])
+    rows = []
+    for k in range(20):
+        s.step_n(0.001, 1000)
+        st = s.get_state()
+        rows.append(np.concatenate([st["x"][0], st["v"][0], st["R"][0].ravel(), st["omega"][0], st["motor_rpm"][0, :4], s.get_imu()[0]]))
+    out["config1_every_1000_steps"] = np.array(rows)
+
+    rng = np.random.default_rng(64)
+    n = 64
+    s = O.OracleSwarm(n)
+    names = ["x500", "f550", "naki", "t650"]
+    modes, payloads = [], []
+    st0 = helpers.random_state(rng, n, 8, tilted=True)
+    for i in range(n):
+        af = names[i % 4]
+        s.construct(i, 1, helpers.oracle_params(af), [st0["x"][i]], [0.0])
+        for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+            getattr(s, nm)(i, 1)
+    s.set_state(0, n, st0["x"], st0["v"], st0["R"], st0["omega"], st0["motor_rpm"])
+    for i in range(n):
+        mode = [O.POSITION_CMD, O.VELOCITY_HDG_CMD, O.ACCELERATION_HDG_RATE_CMD, O.ATTITUDE_RATE_CMD, O.ACTUATOR_CMD][i % 5]
+        if mode == O.ACTUATOR_CMD:
+            pl = np.concatenate([rng.uniform(0.4, 0.6, 8)])
+        elif mode == O.POSITION_CMD:
+            pl = np.concatenate([st0["x"][i] + rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 1)])
+        elif mode == O.ATTITUDE_RATE_CMD:
+            pl = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(0.4, 0.6, 1)])
+        else:
+            pl = np.concatenate([rng.uniform(-2, 2, 3), rng.uniform(-1, 1, 1)])
+        pl = np.pad(pl, (0, 8 - len(pl)))
+        s.set_input(i, 1, mode, pl[None, :])
+        modes.append(mode)
+        payloads.append(pl)
+    s.step_n(0.001, 200)
+    st = s.get_state()
+    out.update(mixed_x0=st0["x"], mixed_v0=st0["v"], mixed_R0=st0["R"], mixed_w0=st0["omega"], mixed_rpm0=st0["motor_rpm"],
+               mixed_modes=np.array(modes), mixed_payloads=np.array(payloads), mixed_x=st["x"], mixed_v=st["v"], mixed_R=st["R"],
+               mixed_w=st["omega"], mixed_rpm=st["motor_rpm"], mixed_imu=s.get_imu(), mixed_pid=s.get_pid())
+    np.savez_compressed(os.path.join(HERE, "oracle_trajectories.npz"), **out)
+
+
+if __name__ == "__main__":
+    nanoflann_sets()
+    oracle_trajectories()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

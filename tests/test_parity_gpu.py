@@ -455,3 +455,29 @@ def test_set_state_keeps_v_prev_like_the_reference(M, oracle):
     p.both("apply_force", 0, 20, rng.normal(0, 3, (20, 3)))  # first force ever applied to this swarm
     p.step(DT, 2)
     p.compare(RTOL_LITERAL, "external force switched on")
+
+
+def test_c_abi_error_codes(M):
+    """The reference's API cannot fail; the C ABI reports misuse through return codes (surfaced as MrsError)."""
+    s = M.Swarm(10)
+    with pytest.raises(M.MrsError, match="range"):
+        s.step_n(DT, 1) or s.get_state(8, 5)
+    with pytest.raises(M.MrsError, match="range"):
+        s.set_input(5, 6, M.POSITION_CMD, np.zeros((6, 4)))
+    with pytest.raises(M.MrsError, match="mode"):
+        s.set_input(0, 1, 11, np.zeros((1, 4)))
+    with pytest.raises(M.MrsError, match="stride|payload"):
+        s.set_input(0, 1, M.ATTITUDE_CMD, np.zeros((1, 4)))
+    with pytest.raises(M.MrsError, match="n_motors|narrower"):
+        s.construct(0, 1, M.model_params("naki"))
+        s.set_input(0, 1, M.ACTUATOR_CMD, np.zeros((1, 4)))
+    with pytest.raises(M.MrsError):
+        s.step_n(-1.0, 1)
+    p = M.model_params("x500")
+    p.n_motors = 9
+    with pytest.raises(M.MrsError, match="n_motors"):
+        s.construct(0, 1, p)
+    e = M.Swarm(0)  # empty swarm: everything is a no-op
+    e.step_n(DT, 3)
+    e.handle_collisions(True, False, 100.0)
+    assert e.get_state()["x"].shape == (0, 3)
