@@ -76,6 +76,17 @@ typedef struct {
   uint64_t nan_rollback;
 } mrs_diag_t;
 
+/* what UavSystemRos publishes per UAV and tick (src/uav_system_ros.cpp:342-466) and MultirotorSimulator::publishPoses
+ * (src/multirotor_simulator.cpp:365-389), derived on the device and downloaded as one packed array */
+typedef struct {
+  double position[3];            /* odom.pose.pose.position                                  :352-354 */
+  double orientation[4];         /* x, y, z, w of mrs_lib::AttitudeConverter(state.R) == Eigen::Quaterniond(R)  :350 */
+  double velocity_body[3];       /* odom.twist.twist.linear = R^T v                          :356-360 */
+  double angular_velocity[3];    /* odom/imu angular velocity = omega                         :362-364,380-382 */
+  double linear_acceleration[3]; /* imu.linear_acceleration = getImuAcceleration()            :384-388 */
+  double range;                  /* rangefinder: (z - ground_z)/cos(tilt) + 0.01, >40 -> 41, body_z.z <= 0 -> 41  :403-419 */
+} mrs_uav_output_t;
+
 typedef struct mrs_swarm mrs_swarm_t;
 
 /* ---- parameter helpers (host only) ---- */
@@ -158,6 +169,9 @@ int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, d
 /* PID internals for parity checks: count x 24 = {position,velocity,attitude,rate} x {x,y,z} x {last_error, integral} */
 int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid);
 int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out);
+/* publishOdometry + publishIMU + publishRangefinder + publishPoses payloads of UAVs [first, first+count): one pack kernel,
+ * one device-to-host copy (src/uav_system_ros.cpp:342-431, src/multirotor_simulator.cpp:365-389) */
+int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out);
 
 /* ---- multi-GPU collision exchange (one swarm shard per process/GPU) ---- */
 /* device pointer + byte size of this shard's packed {x,y,z,mass,arm_length,prop_radius} records (48 B/UAV), refreshed by

@@ -16,6 +16,7 @@ UNITS = [
     ("step_kernel_literal.hip", "off"),
     ("step_kernel_fast.hip", "fast"),
     ("collide.hip", "off"),
+    ("outputs.hip", "off"),
     ("swarm_host.hip", "off"),
 ]
 DEPS = ["step_device.inc", "swarm_layout.h", os.path.join("..", "..", "include", "mrs_swarm.h")]

@@ -1,0 +1,94 @@
+// outputs.hip — per-UAV publisher payloads derived on the device and packed for ONE device-to-host copy.
+// Replaces the per-UAV host work of UavSystemRos::publishOdometry/IMU/Rangefinder (src/uav_system_ros.cpp:342-431)
+// and MultirotorSimulator::publishPoses (src/multirotor_simulator.cpp:365-389): state never leaves HBM column by column.
+// HBM-bound gather: reads 22 doubles + flags per UAV (coalesced SoA columns), writes one 136-B record.
+#include <hip/hip_runtime.h>
+
+#include "../../include/mrs_swarm.h"
+#include "swarm_layout.h"
+
+namespace {
+
+// Eigen::Quaterniond(Matrix3d) (what mrs_lib::AttitudeConverter(R) stores): Eigen/src/Geometry/Quaternion.h,
+// quaternionbase_assign_impl<Other,3,3>.  R row-major; q = {x, y, z, w}.
+__device__ __forceinline__ void quat_from_matrix(const double m[9], double q[4]) {
+  double t = (m[0] + m[4]) + m[8];
+  if (t > 0) {
+    t    = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t    = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    // i = argmax of the diagonal with Eigen's tie rules; written without dynamic register indexing
+    const bool i1 = m[4] > m[0];
+    const double mi1 = i1 ? m[4] : m[0];
+    const bool i2 = m[8] > mi1;
+    if (i2) {  // i=2, j=0, k=1
+      t    = sqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t;
+      t    = 0.5 / t;
+      q[3] = (m[3] - m[1]) * t;  // (m(k,j) - m(j,k)) = m(1,0) - m(0,1)
+      q[0] = (m[2] + m[6]) * t;  // (m(j,i) + m(i,j)) = m(0,2) + m(2,0)
+      q[1] = (m[5] + m[7]) * t;  // (m(k,i) + m(i,k)) = m(1,2) + m(2,1)
+    } else if (i1) {  // i=1, j=2, k=0
+      t    = sqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t;
+      t    = 0.5 / t;
+      q[3] = (m[2] - m[6]) * t;  // m(0,2) - m(2,0)
+      q[2] = (m[7] + m[5]) * t;  // m(2,1) + m(1,2)
+      q[0] = (m[1] + m[3]) * t;  // m(0,1) + m(1,0)
+    } else {  // i=0, j=1, k=2
+      t    = sqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t;
+      t    = 0.5 / t;
+      q[3] = (m[7] - m[5]) * t;  // m(2,1) - m(1,2)
+      q[1] = (m[3] + m[1]) * t;  // m(1,0) + m(0,1)
+      q[2] = (m[6] + m[2]) * t;  // m(2,0) + m(0,2)
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int    i  = first + k;
+  const size_t np = (size_t)sw.npad;
+#define LD(f) sw.S[(f) * np + i]
+  double x[3], v[3], R[9], w[3], imu[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    x[c] = LD(F_X + c); v[c] = LD(F_V + c); w[c] = LD(F_W + c); imu[c] = LD(F_IMU + c);
+  }
+#pragma unroll
+  for (int c = 0; c < 9; c++) R[c] = LD(F_R + c);
+#undef LD
+  const double ground_z = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT].ground_z;
+  mrs_uav_output_t o;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    o.position[c]            = x[c];
+    o.angular_velocity[c]    = w[c];
+    o.linear_acceleration[c] = imu[c];
+    o.velocity_body[c]       = (R[c] * v[0] + R[3 + c] * v[1]) + R[6 + c] * v[2];  // R^T v, src/uav_system_ros.cpp:356
+  }
+  quat_from_matrix(R, o.orientation);
+  // publishRangefinder, :403-419: dot(-body_z, (0,0,-1)) = ((-bz0)*0 + (-bz1)*0) + (-bz2)*(-1)
+  const double bz2  = R[8];
+  const double dot  = ((-R[2]) * 0.0 + (-R[5]) * 0.0) + (-bz2) * (-1.0);
+  const double tilt = acos(dot);
+  double       range = 1.7976931348623157e308;
+  if (bz2 > 0) range = (x[2] - ground_z) / cos(tilt) + 0.01;
+  if (range > 40.0) range = 41.0;
+  o.range = range;
+  out[k]  = o;
+}
+
+}  // namespace
+
+extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_outputs, dim3((count + 255) / 256), dim3(256), 0, st, sw, first, count, dev_out);
+  return hipGetLastError();
+}

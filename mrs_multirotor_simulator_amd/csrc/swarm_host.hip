@@ -29,6 +29,8 @@ struct CollideWork;
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                       int crash, double rebounce, hipStream_t st);
 extern "C" void mrs_collide_free(CollideWork* w);
+// outputs.hip
+extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -225,6 +227,10 @@ struct mrs_swarm {
   int64_t n_cascade = 0;              // UAVs whose mode needs the controller cascade
   bool   types_dirty = true;
   double table_dt    = -1.0;
+  // publisher payloads: device pack buffer + pinned host staging
+  mrs_uav_output_t* dOut = nullptr;
+  mrs_uav_output_t* hOut = nullptr;
+  int32_t           out_cap = 0;
   // collision scratch
   PosRecord*   dRec = nullptr;
   CollideWork* cwork = nullptr;
@@ -521,6 +527,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   for (auto e : s->ev) (void)hipEventDestroy(e);
   mrs_collide_free(s->cwork);
   if (s->dRec) (void)hipFree(s->dRec);
+  if (s->dOut) (void)hipFree(s->dOut);
+  if (s->hOut) (void)hipHostFree(s->hOut);
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
@@ -959,6 +967,28 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
   out->projected_norm_small = d[1];
   out->yaw_rate_not_finite  = d[2];
   out->nan_rollback         = d[3];
+  return MRS_OK;
+}
+
+int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  if (count > s->out_cap) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->dOut) HIPCHK(hipFree(s->dOut));
+    if (s->hOut) HIPCHK(hipHostFree(s->hOut));
+    HIPCHK(hipMalloc(&s->dOut, sizeof(mrs_uav_output_t) * (size_t)count));
+    HIPCHK(hipHostMalloc(&s->hOut, sizeof(mrs_uav_output_t) * (size_t)count, hipHostMallocDefault));
+    s->out_cap = count;
+  }
+  HIPCHK(mrs_launch_pack_outputs(s->view(), first, count, s->dOut, s->stream));
+  HIPCHK(hipMemcpyAsync(s->hOut, s->dOut, sizeof(mrs_uav_output_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  memcpy(out, s->hOut, sizeof(mrs_uav_output_t) * (size_t)count);
   return MRS_OK;
 }
 

@@ -50,6 +50,16 @@ class PositionParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("kp", "kd", "ki", "max_velocity")]
 
 
+class UavOutput(C.Structure):
+    """mrs_uav_output_t: what UavSystemRos publishes per UAV and tick."""
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("velocity_body", C.c_double * 3),
+                ("angular_velocity", C.c_double * 3), ("linear_acceleration", C.c_double * 3), ("range", C.c_double)]
+
+
+OUTPUT_DTYPE = np.dtype([("position", "f8", 3), ("orientation", "f8", 4), ("velocity_body", "f8", 3),
+                         ("angular_velocity", "f8", 3), ("linear_acceleration", "f8", 3), ("range", "f8")])
+
+
 class Diag(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("hdg_rate_denom_small", "projected_norm_small", "yaw_rate_not_finite",
                                           "nan_rollback")]
@@ -65,7 +75,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_set_input", "mrs_swarm_set_feedforward", "mrs_swarm_apply_force", "mrs_swarm_crash",
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
-    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
+    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -137,6 +147,7 @@ def load_library():
         "mrs_swarm_get_external_force": [vp, i32, i32, dp],
         "mrs_swarm_get_pid": [vp, i32, i32, dp],
         "mrs_swarm_get_diag": [vp, C.POINTER(Diag)],
+        "mrs_swarm_get_outputs": [vp, i32, i32, vp],
         "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
@@ -327,6 +338,14 @@ class Swarm:
 
     def get_pid(self, first=0, count=None):
         return self._get3(_lib.mrs_swarm_get_pid, first, count, 24)
+
+    def get_outputs(self, first=0, count=None):
+        """odom / imu / rangefinder / pose payloads as a structured array (one pack kernel + one D2H copy)."""
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=OUTPUT_DTYPE)
+        assert out.dtype.itemsize == C.sizeof(UavOutput)
+        _check(_lib.mrs_swarm_get_outputs(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def get_diag(self):
         d = Diag()

@@ -51,6 +51,10 @@ class Diag(C.Structure):
                                           "nan_rollback")]
 
 
+OUTPUT_DTYPE = np.dtype([("position", "f8", 3), ("orientation", "f8", 4), ("velocity_body", "f8", 3),
+                         ("angular_velocity", "f8", 3), ("linear_acceleration", "f8", 3), ("range", "f8")])
+
+
 def build(force=False):
     """make -C oracle (liboracle.so always; _ref only when /root/reference exists)."""
     so = os.path.join(HERE, "liboracle.so")
@@ -100,6 +104,7 @@ def lib():
         L.orc_swarm_get_pid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
         L.orc_swarm_get_mixer_allocation.argtypes = [C.c_void_p, C.c_int32, dp]
         L.orc_swarm_get_diag.argtypes = [C.c_void_p, C.POINTER(Diag)]
+        L.orc_swarm_get_outputs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.orc_pid_update.restype = C.c_double
         L.orc_pid_update.argtypes = [C.c_double] * 5 + [dp, dp, C.c_double, C.c_double]
         L.orc_llt_reorth.argtypes = [dp, dp]
@@ -241,6 +246,12 @@ class OracleSwarm:
         n = self.get_params(uav).n_motors
         out = np.zeros((n, 4))
         lib().orc_swarm_get_mixer_allocation(self._h, uav, _dp(out))
+        return out
+
+    def get_outputs(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=OUTPUT_DTYPE)
+        lib().orc_swarm_get_outputs(self._h, first, count, out.ctypes.data_as(C.c_void_p))
         return out
 
     def get_diag(self):

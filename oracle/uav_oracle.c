@@ -1255,3 +1255,55 @@ void orc_swarm_get_mixer_allocation(const orc_swarm_t* s, int32_t uav, double* o
   memcpy(out, s->u[uav].alloc_inv, sizeof(double) * 4 * (size_t)s->u[uav].p.n_motors);
 }
 void orc_swarm_get_diag(const orc_swarm_t* s, orc_diag_t* out) { *out = s->diag; }
+
+/* Eigen::Quaterniond(Matrix3d) — Eigen/src/Geometry/Quaternion.h quaternionbase_assign_impl<Other,3,3>::run.
+ * q = {x, y, z, w} */
+static void quat_from_matrix(const double m[9], double q[4]) {
+  double t = (M3(m, 0, 0) + M3(m, 1, 1)) + M3(m, 2, 2);
+  if (t > 0) {
+    t    = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t    = 0.5 / t;
+    q[0] = (M3(m, 2, 1) - M3(m, 1, 2)) * t;
+    q[1] = (M3(m, 0, 2) - M3(m, 2, 0)) * t;
+    q[2] = (M3(m, 1, 0) - M3(m, 0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M3(m, 1, 1) > M3(m, 0, 0)) i = 1;
+    if (M3(m, 2, 2) > M3(m, i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t    = sqrt(M3(m, i, i) - M3(m, j, j) - M3(m, k, k) + 1.0);
+    q[i] = 0.5 * t;
+    t    = 0.5 / t;
+    q[3] = (M3(m, k, j) - M3(m, j, k)) * t;
+    q[j] = (M3(m, j, i) + M3(m, i, j)) * t;
+    q[k] = (M3(m, k, i) + M3(m, i, k)) * t;
+  }
+}
+
+void orc_swarm_get_outputs(const orc_swarm_t* s, int32_t first, int32_t count, orc_uav_output_t* out) {
+  for (int n = 0; n < count; n++) {
+    const uav_t*      u = &s->u[first + n];
+    orc_uav_output_t* o = &out[n];
+    double            Rt[9];
+    memcpy(o->position, u->x, sizeof u->x);             /* src/uav_system_ros.cpp:352-354 */
+    quat_from_matrix(u->R, o->orientation);             /* :350 */
+    mat3_transpose(u->R, Rt);
+    mat3_vec(Rt, u->v, o->velocity_body);               /* :356 */
+    memcpy(o->angular_velocity, u->omega, sizeof u->omega);
+    memcpy(o->linear_acceleration, u->imu, sizeof u->imu);
+    /* publishRangefinder, :403-419 */
+    const double body_z[3]          = {M3(u->R, 0, 2), M3(u->R, 1, 2), M3(u->R, 2, 2)};
+    const double rangefinder_dir[3] = {-body_z[0], -body_z[1], -body_z[2]};
+    const double down[3]            = {0, 0, -1};
+    double       tilt = acos(vec3_dot(rangefinder_dir, down));
+    double       range;
+    if (body_z[2] > 0) {
+      range = (u->x[2] - u->p.ground_z) / cos(tilt) + 0.01;
+    } else {
+      range = 1.7976931348623157e308;
+    }
+    if (range > 40.0) range = 41.0;
+    o->range = range;
+  }
+}

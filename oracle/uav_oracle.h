@@ -80,6 +80,11 @@ typedef struct {
   uint64_t nan_rollback;           /* multirotor_model.hpp:228-233 */
 } orc_diag_t;
 
+/* per-UAV publisher payloads, src/uav_system_ros.cpp:342-431 */
+typedef struct {
+  double position[3], orientation[4] /* x y z w */, velocity_body[3], angular_velocity[3], linear_acceleration[3], range;
+} orc_uav_output_t;
+
 typedef struct orc_swarm orc_swarm_t;
 
 /* defaults of the ModelParams ctor (x500), multirotor_model.hpp:26-66; ground_z := 0 (uninitialised in the reference) */
@@ -145,6 +150,11 @@ void orc_swarm_get_pid(const orc_swarm_t* s, int32_t first, int32_t count, doubl
 /* Mixer::getAllocationMatrix, mixer.hpp:150: n_motors x 4 row-major */
 void orc_swarm_get_mixer_allocation(const orc_swarm_t* s, int32_t uav, double* out);
 void orc_swarm_get_diag(const orc_swarm_t* s, orc_diag_t* out);
+/* publishOdometry / publishIMU / publishRangefinder payloads (src/uav_system_ros.cpp:342-431).  The orientation is
+ * mrs_lib::AttitudeConverter(R) — mrs_lib (ctu-mrs/mrs_lib, version unpinned by package.xml:20) is NOT in the reference tree;
+ * its published implementation forwards to Eigen::Quaterniond(R), whose algorithm (Eigen/src/Geometry/Quaternion.h,
+ * quaternionbase_assign_impl<Other,3,3>) is restated here. */
+void orc_swarm_get_outputs(const orc_swarm_t* s, int32_t first, int32_t count, orc_uav_output_t* out);
 
 /* building blocks exposed for known-answer tests */
 double orc_pid_update(double kp, double kd, double ki, double saturation, double antiwindup,

@@ -1,0 +1,79 @@
+"""Publisher payloads (odometry / IMU / rangefinder / poses) — SURVEY §8f rank 2.  CPU: the oracle's restatement of
+Eigen::Quaterniond(R) (what mrs_lib::AttitudeConverter stores) and of publishRangefinder against independent maths;
+GPU: the packed device derivation against the oracle."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import helpers
+
+
+def special_rotations():
+    rs = [np.eye(3), np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, 1.0, -1.0]), np.diag([-1.0, -1.0, 1.0])]
+    for ax, ang in (([1, 0, 0], 3.0), ([0, 1, 0], 3.1), ([0, 0, 1], -3.05), ([1, 1, 0], 2.9), ([0.2, 1, 1], 3.13), ([1, 0.1, 1], np.pi)):
+        rs.append(Rotation.from_rotvec(np.array(ax, float) / np.linalg.norm(ax) * ang).as_matrix())
+    return np.array(rs)
+
+
+def scenario(O, rng, n):
+    R = np.concatenate([special_rotations(), helpers.random_rotations(rng, n - len(special_rotations()))])
+    st = helpers.random_state(rng, n, 4)
+    st["R"] = R
+    st["x"][:, 2] = rng.uniform(0.0, 60.0, n)  # some beyond the 40 m range limit once tilted
+    return st
+
+
+def test_oracle_outputs_known_answers(oracle):
+    O = oracle
+    rng = np.random.default_rng(5)
+    n = 300
+    st = scenario(O, rng, n)
+    s = O.OracleSwarm(n)
+    p = helpers.oracle_params("x500", ground_enabled=True, ground_z=1.5)
+    s.construct(0, n, p)
+    s.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    s.set_input(0, n, O.ACTUATOR_CMD, np.full((n, 4), 0.5))
+    s.step(0.001)  # gives a non-trivial IMU value
+    st = s.get_state()
+    o = s.get_outputs()
+    assert np.array_equal(o["position"], st["x"]) and np.array_equal(o["angular_velocity"], st["omega"])
+    assert np.array_equal(o["linear_acceleration"], s.get_imu())
+    assert np.allclose(o["velocity_body"], np.einsum("nji,nj->ni", st["R"], st["v"]), rtol=1e-14, atol=1e-14)
+    q_ref = Rotation.from_matrix(st["R"]).as_quat()  # x y z w
+    sign = np.sign(np.sum(q_ref * o["orientation"], axis=1, keepdims=True))
+    assert np.allclose(o["orientation"] * sign, q_ref, atol=1e-9)
+    assert np.allclose(np.linalg.norm(o["orientation"], axis=1), 1.0, atol=1e-9)
+    # Eigen's branch: w >= 0 when trace > 0
+    tr = np.trace(st["R"], axis1=1, axis2=2)
+    assert np.all(o["orientation"][tr > 0, 3] > 0)
+    bz = st["R"][:, 2, 2]
+    exp = np.where(bz > 0, (st["x"][:, 2] - 1.5) / np.where(bz > 0, bz, 1.0) + 0.01, np.inf)
+    exp = np.where(exp > 40.0, 41.0, exp)
+    assert np.allclose(o["range"], exp, rtol=1e-12)
+    assert (o["range"] == 41.0).sum() > 10 and (o["range"] < 40).sum() > 10
+
+
+def test_identity_and_half_turns(oracle):
+    s = oracle.OracleSwarm(4)
+    R = np.array([np.eye(3), np.diag([1.0, -1, -1]), np.diag([-1.0, 1, -1]), np.diag([-1.0, -1, 1])])
+    s.set_state(0, 4, np.zeros((4, 3)), np.zeros((4, 3)), R, np.zeros((4, 3)), np.zeros((4, 8)))
+    q = s.get_outputs()["orientation"]
+    assert np.array_equal(q, [[0, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])
+
+
+@pytest.mark.gpu
+def test_gpu_outputs_match_oracle(mrs, oracle):
+    rng = np.random.default_rng(6)
+    n = 3000
+    p = helpers.Pair(mrs, n)
+    p.construct(0, 1500, "x500", ground_enabled=True, ground_z=1.5)
+    p.construct(1500, 1500, "f550", ground_enabled=True, ground_z=-2.0)
+    p.set_state(0, n, scenario(oracle, rng, n))
+    p.both("set_input", 0, 1500, oracle.ACTUATOR_CMD, np.full((1500, 4), 0.5))
+    p.both("set_input", 1500, 1500, oracle.ACTUATOR_CMD, np.full((1500, 6), 0.5))
+    p.step(0.001, 2)
+    a, b = p.g.get_outputs(), p.o.get_outputs()
+    for k in ("position", "orientation", "velocity_body", "angular_velocity", "linear_acceleration", "range"):
+        helpers.assert_close(a[k], b[k], 1e-12, k)
+    sub = p.g.get_outputs(1490, 20)
+    assert np.array_equal(sub["position"], a["position"][1490:1510]) and np.array_equal(sub["range"], a["range"][1490:1510])
