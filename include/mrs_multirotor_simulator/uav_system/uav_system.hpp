@@ -234,6 +234,25 @@ public:
   }
   void synchronize() { mrs_throw_on_error(mrs_swarm_synchronize(s_)); }
 
+  // ---- UavSystemRos semantics that live on the device ----
+  // timeoutInput() for UAVs [first, first+count): safe command of the same mode (src/uav_system_ros.cpp:474-647)
+  void timeoutInput(int first, int count) { mrs_throw_on_error(mrs_swarm_timeout_input(s_, first, count)); }
+  // callbackSetMass / callbackSetGroundZ (src/uav_system_ros.cpp:1028-1080)
+  void setMass(int first, int count, double mass) { mrs_throw_on_error(mrs_swarm_set_mass(s_, first, count, mass)); }
+  void setGroundZ(int first, int count, double ground_z) { mrs_throw_on_error(mrs_swarm_set_ground_z(s_, first, count, ground_z)); }
+  // what publishOdometry / publishIMU / publishRangefinder / publishPoses need, one packed download
+  std::vector<mrs_uav_output_t> getOutputs(int first, int count) {
+    std::vector<mrs_uav_output_t> out((size_t)count);
+    mrs_throw_on_error(mrs_swarm_get_outputs(s_, first, count, out.data()));
+    return out;
+  }
+  // the tail of the UavSystemRos constructor (:223-232) for the whole swarm: zero actuators, two makeStep(0.01)
+  void warmUp() {
+    std::vector<double> zeros((size_t)size() * MRS_MAX_MOTORS, 0.0);
+    mrs_throw_on_error(mrs_swarm_set_input(s_, 0, size(), MRS_ACTUATOR_CMD, zeros.data(), MRS_MAX_MOTORS));
+    mrs_throw_on_error(mrs_swarm_step_n(s_, 0.01, 2, 1));
+  }
+
   // getPose() of every UAV (src/uav_system_ros.cpp:289), n x 3 row-major
   std::vector<double> getPoses() {
     std::vector<double> x((size_t)size() * 3);

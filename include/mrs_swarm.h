@@ -142,6 +142,17 @@ int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const do
 int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count);
 int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out);
 
+/* ---- UavSystemRos semantics that touch device state ---- */
+/* UavSystemRos::timeoutInput — src/uav_system_ros.cpp:474-647: the command of every UAV in [first, first+count) is replaced
+ * by the safe command of its current input mode (hold position / zero velocity / level attitude / zero rates / zero
+ * motors), computed on the device from the current state; heading = mrs_lib::AttitudeConverter(R).getHeading() */
+int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count);
+/* UavSystemRos::callbackSetMass — :1028-1053 (allocation row 2 rescaled by m_new/m_old, inertia recomputed, setParams:
+ * controllers fall back to DEFAULT gains with fresh PIDs) */
+int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass);
+/* UavSystemRos::callbackSetGroundZ — :1055-1080 (also through setParams: gains reset) */
+int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double ground_z);
+
 /* ---- the hot path ---- */
 /* for (i) uavs_[i]->makeStep(dt) — src/multirotor_simulator.cpp:211-213 -> UavSystem::makeStep, uav_system.hpp:304-380.
  * Asynchronous on the swarm's stream. */

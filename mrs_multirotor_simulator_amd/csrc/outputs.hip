@@ -85,7 +85,82 @@ __global__ void __launch_bounds__(256) k_pack_outputs(SwarmDev sw, int first, in
   out[k]  = o;
 }
 
+// mrs_lib::AttitudeConverter(R).getHeading(): q = Eigen::Quaterniond(R); heading = atan2 of the first column of
+// tf2::Matrix3x3::setRotation(q) (tf2::Transform(q) * (1,0,0))
+__device__ __forceinline__ double heading_of(const double R[9]) {
+  double q[4];
+  quat_from_matrix(R, q);
+  const double d  = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+  const double sc = 2.0 / d;
+  const double ys = q[1] * sc, zs = q[2] * sc;
+  const double wz = q[3] * zs, xy = q[0] * ys, yy = q[1] * ys, zz = q[2] * zs;
+  return atan2(xy + wz, 1.0 - (yy + zz));
+}
+
+// UavSystemRos::timeoutInput (src/uav_system_ros.cpp:474-647) for one UAV per lane: the command columns are overwritten
+// with the safe command of the UAV's current input mode; state stays on the device.
+__global__ void __launch_bounds__(256) k_timeout_input(SwarmDev sw, int first, int count) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int      i    = first + k;
+  const size_t   np   = (size_t)sw.npad;
+  const uint32_t fl   = sw.F[i];
+  const int      mode = (int)((fl & FLAG_MODE_MASK) >> FLAG_MODE_SHIFT);
+#define CMD(q) sw.S[(F_CMD + (q)) * np + i]
+  double R[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) R[c] = sw.S[(F_R + c) * np + i];
+  switch (mode) {
+    case MRS_POSITION_CMD:
+      CMD(0) = sw.S[(F_X + 0) * np + i]; CMD(1) = sw.S[(F_X + 1) * np + i]; CMD(2) = sw.S[(F_X + 2) * np + i];
+      CMD(3) = heading_of(R);
+      break;
+    case MRS_VELOCITY_HDG_CMD:
+    case MRS_ACCELERATION_HDG_CMD:
+      CMD(0) = 0.0; CMD(1) = 0.0; CMD(2) = 0.0;
+      CMD(3) = heading_of(R);
+      break;
+    case MRS_VELOCITY_HDG_RATE_CMD:
+    case MRS_ACCELERATION_HDG_RATE_CMD:
+    case MRS_ATTITUDE_RATE_CMD:
+    case MRS_CONTROL_GROUP_CMD:
+      CMD(0) = 0.0; CMD(1) = 0.0; CMD(2) = 0.0; CMD(3) = 0.0;
+      break;
+    case MRS_ATTITUDE_CMD: {
+      // mrs_lib::AttitudeConverter(0, 0, heading): tf2 setRPY, then Eigen Quaternion::toRotationMatrix
+      const double h  = heading_of(R);
+      const double hy = h * 0.5, hp = 0.0 * 0.5, hr = 0.0 * 0.5;
+      const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+      const double x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy, z = cr * cp * sy - sr * sp * cy,
+                   w = cr * cp * cy + sr * sp * sy;
+      const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+                   tzz = tz * z;
+      CMD(0) = 1.0 - (tyy + tzz); CMD(1) = txy - twz;         CMD(2) = txz + twy;
+      CMD(3) = txy + twz;         CMD(4) = 1.0 - (txx + tzz); CMD(5) = tyz - twx;
+      CMD(6) = txz - twy;         CMD(7) = tyz + twx;         CMD(8) = 1.0 - (txx + tyy);
+      CMD(9) = 0.0;
+      break;
+    }
+    case MRS_TILT_HDG_RATE_CMD:
+      CMD(0) = 0.0; CMD(1) = 0.0; CMD(2) = 1.0; CMD(3) = 0.0; CMD(4) = 0.0;
+      break;
+    case MRS_ACTUATOR_CMD:
+#pragma unroll
+      for (int m = 0; m < MRS_MAXM; m++) CMD(m) = 0.0;
+      break;
+    default: break;  // INPUT_UNKNOWN stays INPUT_UNKNOWN
+  }
+#undef CMD
+}
+
 }  // namespace
+
+extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_timeout_input, dim3((count + 255) / 256), dim3(256), 0, st, sw, first, count);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st) {
   if (count <= 0) return hipSuccess;

@@ -30,6 +30,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
                                       int crash, double rebounce, hipStream_t st);
 extern "C" void mrs_collide_free(CollideWork* w);
 // outputs.hip
+extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -429,6 +430,31 @@ static int set_controller_params(mrs_swarm* s, int first, int count, int pid_fie
   if (pid_field >= 0)
     for (int f = pid_field; f < pid_field + 6; f++)
       if ((rc = fill_column(s, f, first, count, 0.0))) return rc;
+  return MRS_OK;
+}
+
+
+// callbackSetMass / callbackSetGroundZ: getParams -> modify -> setParams, UAV by UAV (types are interned, so a uniform range
+// costs one table entry)
+template <class Mutator>
+static int modify_params(mrs_swarm* s, int first, int count, Mutator mutate) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  std::vector<uint32_t> fl((size_t)count);
+  HIPCHK(hipMemcpyAsync(fl.data(), s->dF + first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  int k = 0;
+  while (k < count) {  // runs of UAVs that share (type, take-off flag)
+    int e = k + 1;
+    while (e < count && s->uav_type[(size_t)first + e] == s->uav_type[(size_t)first + k] && ((fl[(size_t)e] ^ fl[(size_t)k]) & FLAG_TAKEOFF) == 0) e++;
+    mrs_model_params_t p   = s->keys[s->uav_type[(size_t)first + k]].mp;
+    p.takeoff_patch_enabled = (fl[(size_t)k] & FLAG_TAKEOFF) ? 1 : 0;  // getParams() carries the mutated flag
+    mutate(p);
+    if ((rc = mrs_swarm_set_params(s, first + k, e - k, &p))) return rc;
+    k = e;
+  }
   return MRS_OK;
 }
 
@@ -968,6 +994,28 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
   out->yaw_rate_not_finite  = d[2];
   out->nan_rollback         = d[3];
   return MRS_OK;
+}
+
+int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(mrs_launch_timeout_input(s->view(), first, count, s->stream));
+  return MRS_OK;  // the mode of every UAV is unchanged (a safe command OF THE SAME MODE is substituted)
+}
+
+int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass) {
+  return modify_params(s, first, count, [&](mrs_model_params_t& p) {  // src/uav_system_ros.cpp:1036-1047
+    const double original_mass = p.mass;
+    p.mass = mass;
+    for (int m = 0; m < p.n_motors; m++) p.allocation_matrix[2 * MRS_MAX_MOTORS + m] = p.mass * (p.allocation_matrix[2 * MRS_MAX_MOTORS + m] / original_mass);
+    mrs_calculate_inertia(&p);
+  });
+}
+
+int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double ground_z) {
+  return modify_params(s, first, count, [&](mrs_model_params_t& p) { p.ground_z = ground_z; });  // :1063-1073
 }
 
 int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {

@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_set_input", "mrs_swarm_set_feedforward", "mrs_swarm_apply_force", "mrs_swarm_crash",
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
-    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
+    "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -148,6 +148,9 @@ def load_library():
         "mrs_swarm_get_pid": [vp, i32, i32, dp],
         "mrs_swarm_get_diag": [vp, C.POINTER(Diag)],
         "mrs_swarm_get_outputs": [vp, i32, i32, vp],
+        "mrs_swarm_timeout_input": [vp, i32, i32],
+        "mrs_swarm_set_mass": [vp, i32, i32, f64],
+        "mrs_swarm_set_ground_z": [vp, i32, i32, f64],
         "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
@@ -338,6 +341,15 @@ class Swarm:
 
     def get_pid(self, first=0, count=None):
         return self._get3(_lib.mrs_swarm_get_pid, first, count, 24)
+
+    def timeout_input(self, first, count):
+        _check(_lib.mrs_swarm_timeout_input(self._h, first, count))
+
+    def set_mass(self, first, count, mass):
+        _check(_lib.mrs_swarm_set_mass(self._h, first, count, float(mass)))
+
+    def set_ground_z(self, first, count, ground_z):
+        _check(_lib.mrs_swarm_set_ground_z(self._h, first, count, float(ground_z)))
 
     def get_outputs(self, first=0, count=None):
         """odom / imu / rangefinder / pose payloads as a structured array (one pack kernel + one D2H copy)."""

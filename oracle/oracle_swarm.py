@@ -105,6 +105,9 @@ def lib():
         L.orc_swarm_get_mixer_allocation.argtypes = [C.c_void_p, C.c_int32, dp]
         L.orc_swarm_get_diag.argtypes = [C.c_void_p, C.POINTER(Diag)]
         L.orc_swarm_get_outputs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_swarm_timeout_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.orc_swarm_set_mass.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
+        L.orc_swarm_set_ground_z.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
         L.orc_pid_update.restype = C.c_double
         L.orc_pid_update.argtypes = [C.c_double] * 5 + [dp, dp, C.c_double, C.c_double]
         L.orc_llt_reorth.argtypes = [dp, dp]
@@ -247,6 +250,15 @@ class OracleSwarm:
         out = np.zeros((n, 4))
         lib().orc_swarm_get_mixer_allocation(self._h, uav, _dp(out))
         return out
+
+    def timeout_input(self, first, count):
+        lib().orc_swarm_timeout_input(self._h, first, count)
+
+    def set_mass(self, first, count, mass):
+        lib().orc_swarm_set_mass(self._h, first, count, float(mass))
+
+    def set_ground_z(self, first, count, ground_z):
+        lib().orc_swarm_set_ground_z(self._h, first, count, float(ground_z))
 
     def get_outputs(self, first=0, count=None):
         count = self.n - first if count is None else count

@@ -1307,3 +1307,100 @@ void orc_swarm_get_outputs(const orc_swarm_t* s, int32_t first, int32_t count, o
     o->range = range;
   }
 }
+
+/* mrs_lib::AttitudeConverter(R).getHeading() (ctu-mrs/mrs_lib src/attitude_converter/attitude_converter.cpp): the stored
+ * quaternion is Eigen::Quaterniond(R); the heading is atan2 of the rotated body-x axis, obtained through
+ * tf2::Transform(q) * (1,0,0), i.e. the first column of tf2::Matrix3x3::setRotation(q). */
+static double heading_of(const double R[9]) {
+  double q[4];
+  quat_from_matrix(R, q);
+  const double d  = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]; /* tf2 Quaternion::length2 */
+  const double sc = 2.0 / d;
+  const double ys = q[1] * sc, zs = q[2] * sc;
+  const double wz = q[3] * zs, xy = q[0] * ys, yy = q[1] * ys, zz = q[2] * zs;
+  const double m00 = 1.0 - (yy + zz), m10 = xy + wz;
+  return atan2(m10, m00);
+}
+
+/* mrs_lib::AttitudeConverter(0, 0, heading) -> Eigen::Matrix3d: tf2::Quaternion::setRPY then Eigen's
+ * Quaternion::toRotationMatrix (Eigen/src/Geometry/Quaternion.h) */
+static void attitude_from_heading(double heading, double R[9]) {
+  const double hy = heading * 0.5, hp = 0.0 * 0.5, hr = 0.0 * 0.5;
+  const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+  const double x = sr * cp * cy - cr * sp * sy, y = cr * sp * cy + sr * cp * sy, z = cr * cp * sy - sr * sp * cy,
+               w = cr * cp * cy + sr * sp * sy;
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+               tzz = tz * z;
+  M3(R, 0, 0) = 1.0 - (tyy + tzz);
+  M3(R, 0, 1) = txy - twz;
+  M3(R, 0, 2) = txz + twy;
+  M3(R, 1, 0) = txy + twz;
+  M3(R, 1, 1) = 1.0 - (txx + tzz);
+  M3(R, 1, 2) = tyz - twx;
+  M3(R, 2, 0) = txz - twy;
+  M3(R, 2, 1) = tyz + twx;
+  M3(R, 2, 2) = 1.0 - (txx + tyy);
+}
+
+void orc_swarm_timeout_input(orc_swarm_t* s, int32_t first, int32_t count) {
+  for (int n = 0; n < count; n++) {
+    uav_t* u = &s->u[first + n];
+    switch (u->active_input) { /* last_input_mode_ == the mode of the last received command */
+      case ORC_POSITION_CMD: /* :482-495 */
+        memcpy(u->pos, u->x, sizeof u->x);
+        u->pos_heading = heading_of(u->R);
+        break;
+      case ORC_VELOCITY_HDG_CMD: /* :497-510 */
+        memset(u->vel_h, 0, sizeof u->vel_h);
+        u->vel_h_heading = heading_of(u->R);
+        break;
+      case ORC_VELOCITY_HDG_RATE_CMD: /* :512-525 */
+        memset(u->vel_hr, 0, sizeof u->vel_hr);
+        u->vel_hr_rate = 0;
+        break;
+      case ORC_ACCELERATION_HDG_CMD: /* :527-540 */
+        memset(u->acc_h, 0, sizeof u->acc_h);
+        u->acc_h_heading = heading_of(u->R);
+        break;
+      case ORC_ACCELERATION_HDG_RATE_CMD: /* :542-555 */
+        memset(u->acc_hr, 0, sizeof u->acc_hr);
+        u->acc_hr_rate = 0;
+        break;
+      case ORC_ATTITUDE_CMD: /* :557-572 */
+        attitude_from_heading(heading_of(u->R), u->attitude_R);
+        u->attitude_throttle = 0.0;
+        break;
+      case ORC_TILT_HDG_RATE_CMD: /* :574-587 (heading_rate keeps its default 0) */
+        u->tilt[0] = 0; u->tilt[1] = 0; u->tilt[2] = 1;
+        u->tilt_heading_rate = 0;
+        u->tilt_throttle     = 0.0;
+        break;
+      case ORC_ATTITUDE_RATE_CMD: memset(u->attitude_rate, 0, sizeof u->attitude_rate); break; /* :589-604 */
+      case ORC_CONTROL_GROUP_CMD: memset(u->control_group, 0, sizeof u->control_group); break; /* :606-621 */
+      case ORC_ACTUATOR_CMD: memset(u->actuators, 0, sizeof u->actuators); break;             /* :623-635 */
+      default: u->active_input = ORC_INPUT_UNKNOWN; break;                                     /* :637-645 */
+    }
+  }
+}
+
+void orc_swarm_set_mass(orc_swarm_t* s, int32_t first, int32_t count, double mass) { /* src/uav_system_ros.cpp:1036-1047 */
+  for (int n = 0; n < count; n++) {
+    uav_t*             u = &s->u[first + n];
+    orc_model_params_t p = u->p; /* getParams(): includes the mutated take-off flag */
+    const double original_mass = p.mass;
+    p.mass = mass;
+    for (int m = 0; m < p.n_motors; m++) p.allocation_matrix[2 * ORC_MAX_MOTORS + m] = p.mass * (p.allocation_matrix[2 * ORC_MAX_MOTORS + m] / original_mass);
+    orc_calculate_inertia(&p);
+    u->p = p;
+    initialize_controllers(u);
+  }
+}
+
+void orc_swarm_set_ground_z(orc_swarm_t* s, int32_t first, int32_t count, double ground_z) { /* :1063-1073 */
+  for (int n = 0; n < count; n++) {
+    uav_t* u      = &s->u[first + n];
+    u->p.ground_z = ground_z;
+    initialize_controllers(u);
+  }
+}

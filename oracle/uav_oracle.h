@@ -154,6 +154,11 @@ void orc_swarm_get_diag(const orc_swarm_t* s, orc_diag_t* out);
  * mrs_lib::AttitudeConverter(R) — mrs_lib (ctu-mrs/mrs_lib, version unpinned by package.xml:20) is NOT in the reference tree;
  * its published implementation forwards to Eigen::Quaterniond(R), whose algorithm (Eigen/src/Geometry/Quaternion.h,
  * quaternionbase_assign_impl<Other,3,3>) is restated here. */
+/* UavSystemRos::timeoutInput, src/uav_system_ros.cpp:474-647 (mrs_lib/tf2 conversions restated from their published sources) */
+void orc_swarm_timeout_input(orc_swarm_t* s, int32_t first, int32_t count);
+/* UavSystemRos::callbackSetMass / callbackSetGroundZ, src/uav_system_ros.cpp:1028-1080 */
+void orc_swarm_set_mass(orc_swarm_t* s, int32_t first, int32_t count, double mass);
+void orc_swarm_set_ground_z(orc_swarm_t* s, int32_t first, int32_t count, double ground_z);
 void orc_swarm_get_outputs(const orc_swarm_t* s, int32_t first, int32_t count, orc_uav_output_t* out);
 
 /* building blocks exposed for known-answer tests */

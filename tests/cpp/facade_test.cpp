@@ -72,6 +72,12 @@ int main() {
     swarm.makeStep(0.001);
     swarm.handleCollisions(true, false, 100.0);
   }
+  swarm.timeoutInput(0, 200);
+  swarm.setMass(100, 50, 2.4);
+  for (int k = 0; k < 50; k++) swarm.makeStep(0.001);
+  std::vector<mrs_uav_output_t> outs = swarm.getOutputs(0, n);
+  std::printf("OUT7 %.17g %.17g %.17g %.17g %.17g\n", outs[7].orientation[3], outs[7].velocity_body[0], outs[7].range, outs[120].position[2],
+              outs[120].linear_acceleration[2]);
   print_state("SWARM7", swarm[7].getState(), swarm[7].getImuAcceleration());
   print_state("SWARM399", swarm[399].getState(), swarm[399].getImuAcceleration());
   return 0;

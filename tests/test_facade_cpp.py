@@ -71,5 +71,12 @@ def test_facade_matches_oracle(mrs, oracle):
     for _ in range(200):
         sw.step(0.001)
         sw.handle_collisions(True, False, 100.0)
+    sw.timeout_input(0, 200)
+    sw.set_mass(100, 50, 2.4)
+    sw.step_n(0.001, 50)
+    o = sw.get_outputs()
+    got = np.array(rows["OUT7"], dtype=float)
+    helpers.assert_close(got, [o["orientation"][7, 3], o["velocity_body"][7, 0], o["range"][7], o["position"][120, 2],
+                               o["linear_acceleration"][120, 2]], 1e-11, "packed outputs")
     check("SWARM7", sw, 7, rtol=helpers.RTOL_LITERAL)
     check("SWARM399", sw, 399, rtol=helpers.RTOL_LITERAL)

@@ -1,0 +1,160 @@
+"""UavSystemRos semantics that touch device state: input-timeout fallback commands, set_mass,
+set_ground_z, and the construction sequence with its two warm-up steps."""
+import math
+
+import numpy as np
+import pytest
+
+import helpers
+
+DT = 0.001
+
+
+def test_oracle_timeout_holds_position_and_heading(oracle):
+    O = oracle
+    rng = np.random.default_rng(1)
+    n = 50
+    s = O.OracleSwarm(n)
+    s.construct(0, n, helpers.oracle_params("x500"))
+    st = helpers.random_state(rng, n, 4, tilted=True)
+    s.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    s.set_input(0, n, O.POSITION_CMD, np.concatenate([st["x"] + 5, np.zeros((n, 1))], axis=1))
+    s.step_n(DT, 300)
+    x_at_timeout = s.get_state()["x"].copy()
+    R = s.get_state()["R"]
+    hdg = np.arctan2(R[:, 1, 0], R[:, 0, 0])
+    s.timeout_input(0, n)
+    s.step_n(DT, 6000)
+    st2 = s.get_state()
+    assert np.allclose(st2["x"], x_at_timeout, atol=0.15)  # the cascade flies back to and holds the timeout position
+    h2 = np.arctan2(st2["R"][:, 1, 0], st2["R"][:, 0, 0])
+    assert np.allclose(np.angle(np.exp(1j * (h2 - hdg))), 0, atol=0.05)
+
+
+def test_oracle_set_mass_equals_manual_procedure(oracle):
+    O = oracle
+    po = helpers.oracle_params("x500", takeoff_patch_enabled=True)
+    a, b = O.OracleSwarm(1), O.OracleSwarm(1)
+    for s in (a, b):
+        s.construct(0, 1, po, [[0, 0, 5.0]], [0.3])
+        s.set_position_params(0, 1, 3.0, 0.2, 0.1, 5.0)
+        s.set_input(0, 1, O.POSITION_CMD, [[1, 1, 6, 0.5]])
+        s.step_n(DT, 50)
+    a.set_mass(0, 1, 2.6)
+    p2 = b.get_params(0)
+    old = p2.mass
+    p2.mass = 2.6
+    for m in range(4):
+        p2.allocation_matrix[2 * 8 + m] = p2.mass * (p2.allocation_matrix[2 * 8 + m] / old)
+    O.lib().orc_calculate_inertia(p2)
+    b.set_params(0, 1, p2)
+    assert bytes(a.get_params(0)) == bytes(b.get_params(0))
+    assert np.all(a.get_pid() == 0)
+    for s in (a, b):
+        s.step_n(DT, 50)
+    assert np.array_equal(a.get_state()["x"], b.get_state()["x"])
+    a.set_ground_z(0, 1, -3.0)
+    assert a.get_params(0).ground_z == -3.0 and a.get_params(0).mass == 2.6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [0, 1])
+def test_gpu_timeout_input_every_mode(mrs, oracle, arith):
+    from test_parity_gpu import payload_for
+    rng = np.random.default_rng(77)
+    per = 64
+    modes = list(range(0, 11))
+    n = per * len(modes)
+    p = helpers.Pair(mrs, n, arith=arith)
+    p.construct(0, n, "x500")
+    st = helpers.random_state(rng, n, 4, tilted=True)
+    p.set_state(0, n, st)
+    for k, mode in enumerate(modes):
+        sub = {key: val[k * per:(k + 1) * per] for key, val in st.items()}
+        p.both("set_input", k * per, per, mode, payload_for(oracle, mode, rng, per, 4, sub))
+    p.step(DT, 30)
+    p.both("timeout_input", 0, n)
+    p.step(DT, 1)
+    p.compare(helpers.RTOL_LITERAL if arith == 0 else helpers.RTOL_FAST, "first step on the fallback commands")
+    p.step(DT, 60)
+    p.compare(helpers.RTOL_LITERAL if arith == 0 else helpers.RTOL_NORTH_STAR, "60 steps on the fallback commands")
+
+
+@pytest.mark.gpu
+def test_gpu_set_mass_and_ground_z(mrs, oracle):
+    rng = np.random.default_rng(78)
+    n = 256
+    p = helpers.Pair(mrs, n)
+    p.construct(0, n, "x500", ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=True,
+                pos=np.concatenate([rng.uniform(-5, 5, (n, 2)), np.zeros((n, 1))], axis=1), heading=rng.uniform(-3, 3, n))
+    thr = np.where(np.arange(n)[:, None] % 2 == 0, 0.9, 0.1) * np.ones((1, 4))
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, thr)
+    p.step(DT, 200)  # even UAVs lift off (take-off patch cleared), odd ones stay on their patch: two flag values per type
+    p.both("set_mass", 10, 100, 2.6)
+    p.both("set_ground_z", 50, 120, -1.0)
+    for i in (0, 10, 11, 60, 61, 120, 200):
+        assert bytes(p.g.get_params(i)) == bytes(helpers.to_product_params(mrs, p.o.get_params(i))), i
+    p.both("set_input", 0, n, oracle.POSITION_CMD, np.concatenate([rng.uniform(-5, 5, (n, 2)), rng.uniform(1, 4, (n, 1)), np.zeros((n, 1))], axis=1))
+    p.step(DT, 100)
+    p.compare(helpers.RTOL_LITERAL, "after set_mass / set_ground_z")
+
+
+@pytest.mark.gpu
+def test_gpu_uav_system_ros_construction_sequence(mrs, oracle):
+    """src/uav_system_ros.cpp:96-157,223-232: inertia, allocation scaling, UavSystem(params, spawn, heading), five
+    set*Params, zero actuators, two makeStep(0.01)."""
+    n = 100
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([rng.uniform(-30, 30, (n, 2)), np.zeros((n, 1))], axis=1)
+    p = helpers.Pair(mrs, n)
+    p.construct(0, n, "t650", pos=pos, heading=rng.uniform(-3.14, 3.14, n), ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, np.zeros((n, 4)))
+    p.step(0.01, 2)
+    p.compare(helpers.RTOL_LITERAL, "warm-up")
+    c = math.exp(-0.01 / 0.03)
+    assert np.allclose(p.g.get_state()["motor_rpm"][:, :4], 875 * (1 - c) * (1 + c), rtol=1e-14)
+    assert np.array_equal(p.g.get_state()["x"], pos)
+
+
+def test_config_loader_layout(mrs):
+    import os
+    from mrs_multirotor_simulator_amd import config
+    cfg = config.load_yaml_files([os.path.join(os.path.dirname(__file__), "golden", "sample_config.yaml")])
+    p = config.model_params_from_config(cfg, "hexa_test")
+    assert (p.n_motors, p.mass, p.ground_enabled, p.ground_z, p.takeoff_patch_enabled) == (6, 2.9, 1, 0.5, 0)
+    assert p.J[0] == 2.9 * (3.0 * 0.30 * 0.30 + 0.12 * 0.12) / 12.0 and p.J[8] == (2.9 * 0.30 * 0.30) / 2.0
+    assert p.allocation_matrix[1 * 8 + 2] == -0.87 * (0.30 * 0.00000014) and p.allocation_matrix[3 * 8 + 5] == 0.00000014
+    ctl = config.controller_params_from_config(cfg)
+    assert ctl["position_controller"] == {"kp": 2.5, "kd": 0.15, "ki": 0.2, "max_velocity": 4.0}
+    assert ctl["rate_controller"]["kp"] == 4.5 and ctl["attitude_controller"]["kp"] == 6.0
+
+
+@pytest.mark.gpu
+def test_gpu_spawn_from_config_matches_oracle(mrs, oracle):
+    import os
+    from mrs_multirotor_simulator_amd import config
+    cfg = config.load_yaml_files([os.path.join(os.path.dirname(__file__), "golden", "sample_config.yaml")])
+    sw, names = config.spawn_swarm_from_config(cfg, arith=mrs.ARITH_LITERAL)
+    assert names == ["alpha", "bravo", "charlie"]
+    O = oracle
+    o = O.OracleSwarm(3)
+    ctl = config.controller_params_from_config(cfg)
+    for i, nm in enumerate(names):
+        pm = config.model_params_from_config(cfg, cfg[nm]["type"])
+        sp = cfg[nm]["spawn"]
+        o.construct(i, 1, O.ModelParams.from_buffer_copy(bytes(pm)), [[sp["x"], sp["y"], sp["z"]]], [sp["heading"]])
+    o.set_mixer_params(0, 3, True)
+    o.set_rate_params(0, 3, **ctl["rate_controller"])
+    o.set_attitude_params(0, 3, **ctl["attitude_controller"])
+    o.set_velocity_params(0, 3, **ctl["velocity_controller"])
+    o.set_position_params(0, 3, **ctl["position_controller"])
+    o.set_input(0, 3, O.ACTUATOR_CMD, np.zeros((3, 8)))
+    o.step_n(0.01, 2)
+    goal = np.array([[2, 2, 3, 0.1], [-2, 5, 4, -0.5], [5, 0, 2, 2.0]])
+    sw.set_input(0, 3, mrs.POSITION_CMD, goal)
+    o.set_input(0, 3, O.POSITION_CMD, goal)
+    sw.step_n(DT, 500)
+    o.step_n(DT, 500)
+    a, b = sw.get_state(), o.get_state()
+    for k in b:
+        helpers.assert_close(a[k], b[k], helpers.RTOL_LITERAL, k)
