@@ -100,6 +100,17 @@ def cpu_baseline(args, st, cmd):
     out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port",
            "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c -O2 -ffp-contract=off, 1 thread "
                      "(the reference's loop is serial, src/multirotor_simulator.cpp:211-213)"}
+    if coll and O.ref_lib() is not None:
+        # the reference's OWN broadphase on the same positions: nanoflann build + one radius search per UAV
+        # (oracle/_ref, compiled from the reference tree) — "kind": "reference" for this part of the tick
+        import ctypes as C
+        pts = np.ascontiguousarray(o.get_state()["x"])
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0:
+            O.ref_lib().ref_nf_build_and_count(pts.ctypes.data_as(C.POINTER(C.c_double)), n, 3.0, 10)
+            reps += 1
+        out["collision_broadphase_reference"] = {"kind": "reference", "ms_per_tick": (time.perf_counter() - t0) / reps * 1e3,
+                                                 "sample": f"nanoflann kd-tree build + {n} radius searches, 1 thread"}
     if not coll:  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
         cores = os.cpu_count() or 1
         k, t0 = 0, time.perf_counter()
@@ -123,7 +134,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched through torch.distributed.run
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     n = args.uavs
@@ -151,7 +163,7 @@ def main():
     def barrier():
         sw.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sw.synchronize()
         torch.cuda.synchronize()
@@ -165,7 +177,7 @@ def main():
     el = time.perf_counter() - t0
     kern_ms, n_launch = sw.last_step_kernel_ms() if sharded is None else (el / args.steps * 1e3, args.steps)
     sw.set_profiling(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -187,14 +199,17 @@ def main():
                        "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and world > 1)
                                        else f"{world} independent shard(s), no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": ("mrs_uav_model_step_" if args.workload == "actuator" else "mrs_uav_step_") + args.arith, "kernel_avg_ms": kern_ms, "launches": n_launch,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": (("mrs_uav_model_step_" if args.workload == "actuator" else "mrs_uav_step_") + args.arith) if not coll
+                         else "whole tick: mrs_uav_step_" + args.arith + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
                          "method": "one hipEvent pair around the timed region on the swarm's stream: elapsed / launches (inter-launch gaps included)"},
         }
+        if coll:
+            out["roofline"]["note"] = "per-kernel times of the tick: profiles/r01_collision_tick_100k_kernel_stats.csv"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, st, cmd)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
