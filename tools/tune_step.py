@@ -15,6 +15,9 @@ VARIANTS = {
     "default": "",
     "w1": "-DMRS_WAVES_PER_SIMD=1",
     "w3": "-DMRS_WAVES_PER_SIMD=3",
+    "unroll2": "-DMRS_STAGE_UNROLL=2",
+    "unroll4": "-DMRS_STAGE_UNROLL=4",
+    "unroll2_w1": "-DMRS_STAGE_UNROLL=2 -DMRS_WAVES_PER_SIMD=1",
 }
 
 
