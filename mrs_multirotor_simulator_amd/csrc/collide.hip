@@ -12,7 +12,8 @@
 // traversal order is not reproducible by any other structure; with <= 1 partner, the usual case, the sum is exact).
 //
 // Pipeline per tick (all on the swarm's stream, HBM-bound integer/index work):
-//   pack      : SoA state + type table -> 48-B PosRecord per UAV            (also the multi-GPU all-gather payload)
+//   pack      : SoA state + type table -> 48-B PosRecord per UAV (the multi-GPU all-gather payload; fused with
+//               hash_count on a single GPU)
 //   hash_count: cell = floor(pos / 1.75 m) (> sqrt(3), so partners sit in the 27 adjacent cells);
 //               bucket = hash(cell) & (T-1); rank = atomicAdd(count[bucket])
 //   alloc     : every 1024-bucket block scans its counts and reserves its slice of `sorted` with one atomicAdd
@@ -72,8 +73,10 @@ __global__ void k_pack_positions(SwarmDev sw, PosRecord* out) {
   out[i] = r;
 }
 
-__global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* count) {
+__global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* count,
+                             uint32_t* cursor) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) *cursor = 0;  // the allocation cursor of this tick (k_alloc_buckets runs after this kernel)
   if (j >= n_total) return;
   const Cell c = cell_of(rec[j].x, rec[j].y, rec[j].z);
   if (!c.ok) {
@@ -83,6 +86,31 @@ __global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t m
   const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
   key[j]  = b;
   rank[j] = atomicAdd(&count[b], 1u);
+}
+
+// single-GPU tick: pack and hash in one pass over the state (the records are still written: the query reads them)
+__global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* count,
+                                  uint32_t* cursor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *cursor = 0;
+  if (i >= sw.n) return;
+  const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
+  PosRecord r;
+  r.x = sw.S[(size_t)(F_X + 0) * sw.npad + i];
+  r.y = sw.S[(size_t)(F_X + 1) * sw.npad + i];
+  r.z = sw.S[(size_t)(F_X + 2) * sw.npad + i];
+  r.mass        = P.mass;
+  r.arm_length  = P.arm_length;
+  r.prop_radius = P.prop_radius;
+  rec[i] = r;
+  const Cell c = cell_of(r.x, r.y, r.z);
+  if (!c.ok) {
+    key[i] = 0xFFFFFFFFu;
+    return;
+  }
+  const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
+  key[i]  = b;
+  rank[i] = atomicAdd(&count[b], 1u);
 }
 
 // ---- bucket storage allocation: one kernel instead of a full prefix sum ----
@@ -374,8 +402,10 @@ extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hip
     if (_e != hipSuccess) return _e; \
   } while (0)
 
+// rec_is_local_scratch: `rec` is this swarm's own (n_total == sw.n) record buffer that has NOT been packed yet — pack and hash
+// are then fused; otherwise `rec` holds ready (gathered) records
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
-                                      int crash, double rebounce, hipStream_t st) {
+                                      int crash, double rebounce, int rec_is_local_scratch, hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
   uint32_t     T = 1024;
@@ -396,8 +426,10 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   T = w->cap_T;  // a larger table from an earlier call is still valid (count[] is all zero between ticks)
   const uint32_t mask = T - 1;
   const unsigned gN   = (unsigned)((n_total + 255) / 256);
-  CK(hipMemsetAsync(w->cursor, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->count);
+  if (rec_is_local_scratch)
+    hipLaunchKernelGGL(k_pack_hash_count, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, w->key, w->rank, w->count, w->cursor);
+  else
+    hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->count, w->cursor);
   hipLaunchKernelGGL(k_alloc_buckets, dim3(T / 1024), dim3(256), 0, st, w->count, w->cell, w->cursor);
   hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->cell, w->sorted);
   hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, w->cell, w->sorted, crash,

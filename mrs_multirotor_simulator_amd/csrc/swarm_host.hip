@@ -27,7 +27,7 @@ extern "C" hipError_t mrs_launch_flags_update(uint32_t* F, int first, int count,
 extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hipStream_t st);
 struct CollideWork;
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
-                                      int crash, double rebounce, hipStream_t st);
+                                      int crash, double rebounce, int rec_is_local_scratch, hipStream_t st);
 extern "C" void mrs_collide_free(CollideWork* w);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
@@ -860,17 +860,21 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
   if (s->n == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   s->fext_active = true;
-  HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, s->stream));
+  HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, 0, s->stream));
   return MRS_OK;
 }
 
 int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, double rebounce) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
-  if (!(crash || enabled)) return MRS_OK;
+  if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
   if (s->n == 0) return MRS_OK;
-  int rc = mrs_swarm_pack_positions(s, nullptr, nullptr);
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
   if (rc) return rc;
-  return mrs_swarm_handle_collisions_gathered(s, s->dRec, s->n, 0, enabled, crash, rebounce);
+  if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
+  s->fext_active = true;
+  HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->dRec, s->n, 0, crash, rebounce, /*rec_is_local_scratch=*/1, s->stream));
+  return MRS_OK;
 }
 
 int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {

@@ -15,9 +15,13 @@ VARIANTS = {
     "default": "",
     "w1": "-DMRS_WAVES_PER_SIMD=1",
     "w3": "-DMRS_WAVES_PER_SIMD=3",
+    "unroll1": "-DMRS_STAGE_UNROLL=1",
     "unroll2": "-DMRS_STAGE_UNROLL=2",
-    "unroll4": "-DMRS_STAGE_UNROLL=4",
-    "unroll2_w1": "-DMRS_STAGE_UNROLL=2 -DMRS_WAVES_PER_SIMD=1",
+    "maxilp": "-mllvm -amdgpu-sched-strategy=max-ilp",
+    "maxilp_w1": "-mllvm -amdgpu-sched-strategy=max-ilp -DMRS_WAVES_PER_SIMD=1",
+    "memclause": "-mllvm -amdgpu-sched-strategy=max-memory-clause",
+    "O2": "-O2",
+    "nolicm": "-mllvm -disable-licm-promotion",
 }
 
 
