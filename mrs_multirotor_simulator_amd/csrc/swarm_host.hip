@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -212,6 +213,9 @@ static void angle_axis_z(double angle, double R[9]) {
 // ------------------------------------------------------------------------------------------------
 
 struct mrs_swarm {
+  // every C-ABI call on a swarm is serialised (the reference's subscriber callbacks run concurrently with timerMain and are
+  // serialised by mutex_uav_system_, src/uav_system_ros.cpp:267,702): recursive because entry points call each other
+  std::recursive_mutex mtx;
   int32_t  n = 0, npad = 0, device = 0;
   int32_t  arith = MRS_ARITH_LITERAL;
   hipStream_t stream = nullptr;
@@ -264,6 +268,10 @@ static void track_mode(mrs_swarm* s, int first, int count, int mode) {
     m = (uint8_t)mode;
   }
 }
+
+#define MRS_LOCK(s)                                           \
+  std::unique_lock<std::recursive_mutex> _lk;                 \
+  if (s) _lk = std::unique_lock<std::recursive_mutex>(const_cast<mrs_swarm*>(s)->mtx)
 
 static int check_range(const mrs_swarm* s, int first, int count) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
@@ -567,24 +575,28 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
 }
 
 int mrs_swarm_size(const mrs_swarm_t* s, int32_t* n) {
+  MRS_LOCK(s);
   if (!s || !n) return fail(MRS_ERR_ARG, "null argument");
   *n = s->n;
   return MRS_OK;
 }
 
 int mrs_swarm_set_arith(mrs_swarm_t* s, int32_t arith) {
+  MRS_LOCK(s);
   if (!s || (arith != MRS_ARITH_LITERAL && arith != MRS_ARITH_FAST)) return fail(MRS_ERR_ARG, "bad arith");
   s->arith = arith;
   return MRS_OK;
 }
 
 int mrs_swarm_stream(const mrs_swarm_t* s, void** stream) {
+  MRS_LOCK(s);
   if (!s || !stream) return fail(MRS_ERR_ARG, "null argument");
   *stream = (void*)s->stream;
   return MRS_OK;
 }
 
 int mrs_swarm_synchronize(mrs_swarm_t* s) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   HIPCHK(hipStreamSynchronize(s->stream));
   return MRS_OK;
@@ -592,6 +604,7 @@ int mrs_swarm_synchronize(mrs_swarm_t* s) {
 
 int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params, const double* pos,
                         const double* heading) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -622,6 +635,7 @@ int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_
 }
 
 int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!params || params->n_motors < 1 || params->n_motors > MRS_MAX_MOTORS) return fail(MRS_ERR_ARG, "bad params");
@@ -638,6 +652,7 @@ int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs
 }
 
 int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out) {
+  MRS_LOCK(s);
   int rc = check_range(s, uav, 1);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -651,28 +666,34 @@ int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out) {
 }
 
 int mrs_swarm_set_mixer_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_mixer_params_t* p) {
+  MRS_LOCK(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   const mrs_mixer_params_t v{p->desaturation ? 1 : 0, 0};
   return set_controller_params(s, first, count, -1, [&](TypeKey& k) { k.mixer = v; });
 }
 int mrs_swarm_set_position_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_position_params_t* p) {
+  MRS_LOCK(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 0, [&](TypeKey& k) { k.pos = *p; });
 }
 int mrs_swarm_set_velocity_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_velocity_params_t* p) {
+  MRS_LOCK(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 6, [&](TypeKey& k) { k.vel = *p; });
 }
 int mrs_swarm_set_attitude_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_attitude_params_t* p) {
+  MRS_LOCK(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 12, [&](TypeKey& k) { k.att = *p; });
 }
 int mrs_swarm_set_rate_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_rate_params_t* p) {
+  MRS_LOCK(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 18, [&](TypeKey& k) { k.rate = *p; });
 }
 
 int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
+  MRS_LOCK(s);
   int rc = check_range(s, uav, 1);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -682,6 +703,7 @@ int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
 }
 
 int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (mode < MRS_INPUT_UNKNOWN || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
@@ -708,6 +730,7 @@ int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mo
 }
 
 int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (kind < 0 || kind > 3 || !payload || stride < 4) return fail(MRS_ERR_ARG, "bad feed-forward arguments");
@@ -719,6 +742,7 @@ int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int3
 }
 
 int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const double* force) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!force) return fail(MRS_ERR_ARG, "null force");
@@ -731,6 +755,7 @@ int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const do
 }
 
 int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   HIPCHK(hipSetDevice(s->device));
@@ -738,6 +763,7 @@ int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
 }
 
 int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -813,6 +839,7 @@ static int finish_profile(mrs_swarm* s) {
 }
 
 int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substeps_per_launch) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(dt > 0) || n_steps < 0 || substeps_per_launch < 1) return fail(MRS_ERR_ARG, "bad step arguments");
   if (s->n == 0 || n_steps == 0) return MRS_OK;
@@ -829,9 +856,11 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   return finish_profile(s);
 }
 
-int mrs_swarm_step(mrs_swarm_t* s, double dt) { return mrs_swarm_step_n(s, dt, 1, 1); }
+int mrs_swarm_step(mrs_swarm_t* s, double dt) {
+  MRS_LOCK(s); return mrs_swarm_step_n(s, dt, 1, 1); }
 
 int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
@@ -844,6 +873,7 @@ int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
 }
 
 int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst) {
+  MRS_LOCK(s);
   if (!s || !dev_dst) return fail(MRS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
@@ -854,6 +884,7 @@ int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst) {
 
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset, int32_t enabled,
                                          int32_t crash, double rebounce) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
   if (!dev_records || n_total < s->n || my_offset < 0 || my_offset + s->n > n_total) return fail(MRS_ERR_ARG, "bad gathered-record arguments");
@@ -865,6 +896,7 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
 }
 
 int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, double rebounce) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
   if (s->n == 0) return MRS_OK;
@@ -878,6 +910,7 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
 }
 
 int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
   if (s->n == 0 || n_ticks == 0) return MRS_OK;
@@ -895,6 +928,7 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
 // ---- state access ----
 int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x, double* v, double* v_prev, double* R, double* omega,
                         double* motor_rpm) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -920,6 +954,7 @@ int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x,
 
 int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
                         const double* omega, const double* motor_rpm) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -958,6 +993,7 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
 }
 
 int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!imu) return fail(MRS_ERR_ARG, "null out");
@@ -968,6 +1004,7 @@ int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu)
 }
 
 int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, double* force) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!force) return fail(MRS_ERR_ARG, "null out");
@@ -978,6 +1015,7 @@ int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, d
 }
 
 int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!pid) return fail(MRS_ERR_ARG, "null out");
@@ -988,6 +1026,7 @@ int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid)
 }
 
 int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
+  MRS_LOCK(s);
   if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
   unsigned long long d[4];
@@ -1001,6 +1040,7 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
 }
 
 int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -1010,6 +1050,7 @@ int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
 }
 
 int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass) {
+  MRS_LOCK(s);
   return modify_params(s, first, count, [&](mrs_model_params_t& p) {  // src/uav_system_ros.cpp:1036-1047
     const double original_mass = p.mass;
     p.mass = mass;
@@ -1019,10 +1060,12 @@ int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass
 }
 
 int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double ground_z) {
+  MRS_LOCK(s);
   return modify_params(s, first, count, [&](mrs_model_params_t& p) { p.ground_z = ground_z; });  // :1063-1073
 }
 
 int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {
+  MRS_LOCK(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -1045,12 +1088,14 @@ int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_
 }
 
 int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   s->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return MRS_OK;
 }
 
 int mrs_swarm_last_step_kernel_ms(mrs_swarm_t* s, double* avg_ms, int32_t* n_launches) {
+  MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (avg_ms) *avg_ms = s->last_ms;
   if (n_launches) *n_launches = s->last_launches;

@@ -481,3 +481,39 @@ def test_c_abi_error_codes(M):
     e.step_n(DT, 3)
     e.handle_collisions(True, False, 100.0)
     assert e.get_state()["x"].shape == (0, 3)
+
+
+def test_concurrent_commands_and_steps(M):
+    """Subscriber callbacks run concurrently with timerMain in the reference (MT node handle + mutex_uav_system_); here every
+    C-ABI call on a swarm is serialised by the library.  ctypes releases the GIL, so the two threads really overlap."""
+    import threading
+    rng = np.random.default_rng(4)
+    n = 2048
+    s = M.Swarm(n, arith=M.ARITH_FAST)
+    s.construct(0, n, M.model_params("x500", ground_enabled=True), np.concatenate([rng.uniform(-50, 50, (n, 2)), np.full((n, 1), 10.0)], axis=1),
+                np.zeros(n))
+    goal = np.concatenate([rng.uniform(-50, 50, (n, 2)), np.full((n, 1), 12.0), np.zeros((n, 1))], axis=1)
+    s.set_input(0, n, M.POSITION_CMD, goal)
+    stop = threading.Event()
+    errors = []
+
+    def commander():
+        k = 0
+        try:
+            while not stop.is_set():
+                lo = (k * 37) % (n - 64)
+                s.set_input(lo, 64, M.POSITION_CMD, goal[lo:lo + 64])
+                s.get_outputs(lo, 64)
+                k += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=commander)
+    t.start()
+    for _ in range(300):
+        s.step_n(DT, 10)
+    stop.set()
+    t.join()
+    assert not errors
+    st = s.get_state()
+    assert np.all(np.isfinite(st["x"])) and np.all(np.abs(st["x"][:, 2] - 12.0) < 3.0)
