@@ -54,6 +54,14 @@ __device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t m
   return (h + (uint32_t)cz) & mask;
 }
 
+// second, independent hash of the exact cell: stored next to every index in `sorted`, it lets the query discard the members of
+// OTHER cells that share a bucket (about 5 per UAV at load factor 0.19) without fetching their 48-B records
+__device__ __forceinline__ uint32_t cell_tag(int cx, int cy, int cz) {
+  uint32_t h = (uint32_t)cx * 0x9E3779B1u + (uint32_t)cy * 0x85EBCA77u + (uint32_t)cz * 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h * 0x27D4EB2Fu;
+}
+
 __global__ void k_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < count) F[first + k] = (F[first + k] & and_mask) | or_mask;
@@ -73,8 +81,8 @@ __global__ void k_pack_positions(SwarmDev sw, PosRecord* out) {
   out[i] = r;
 }
 
-__global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* count,
-                             uint32_t* cursor) {
+__global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* tag,
+                             uint32_t* count, uint32_t* cursor) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) *cursor = 0;  // the allocation cursor of this tick (k_alloc_buckets runs after this kernel)
   if (j >= n_total) return;
@@ -85,12 +93,13 @@ __global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t m
   }
   const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
   key[j]  = b;
+  tag[j]  = cell_tag(c.x, c.y, c.z);
   rank[j] = atomicAdd(&count[b], 1u);
 }
 
 // single-GPU tick: pack and hash in one pass over the state (the records are still written: the query reads them)
-__global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* count,
-                                  uint32_t* cursor) {
+__global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* tag,
+                                  uint32_t* count, uint32_t* cursor) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) *cursor = 0;
   if (i >= sw.n) return;
@@ -110,12 +119,13 @@ __global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, ui
   }
   const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
   key[i]  = b;
+  tag[i]  = cell_tag(c.x, c.y, c.z);
   rank[i] = atomicAdd(&count[b], 1u);
 }
 
 // ---- bucket storage allocation: one kernel instead of a full prefix sum ----
 // Buckets need disjoint slices of `sorted`, not slices in bucket order: each 1024-bucket block scans its own counts
-// in registers/LDS and reserves its total with ONE atomicAdd on a global cursor.  Writes {start, count} per bucket and
+// in registers/LDS and reserves its total with ONE atomicAdd on a global cursor.  Writes start<<6|count per bucket and
 // re-zeroes count[] for the next tick (this kernel is its last reader).
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total) {
   __shared__ uint32_t wsum[4];
@@ -144,19 +154,25 @@ __global__ void __launch_bounds__(256) k_alloc_buckets(uint32_t* count, uint2* c
   __syncthreads();
   const uint32_t s0 = block_base + ex;
   uint2* o = cell + q * 4;
-  o[0] = make_uint2(s0, c.x);
-  o[1] = make_uint2(s0 + c.x, c.y);
-  o[2] = make_uint2(s0 + c.x + c.y, c.z);
-  o[3] = make_uint2(s0 + c.x + c.y + c.z, c.w);
+#define MRS_DESC(start, cnt) make_uint2(((start) << 6) | ((cnt) < 63u ? (cnt) : 63u), 0u)
+  o[0] = MRS_DESC(s0, c.x);
+  o[1] = MRS_DESC(s0 + c.x, c.y);
+  o[2] = MRS_DESC(s0 + c.x + c.y, c.z);
+  o[3] = MRS_DESC(s0 + c.x + c.y + c.z, c.w);
+#undef MRS_DESC
   reinterpret_cast<uint4*>(count)[q] = make_uint4(0, 0, 0, 0);
 }
 
-__global__ void k_scatter(long long n_total, const uint32_t* key, const uint32_t* rank, const uint2* cell, uint32_t* sorted) {
+// Descriptor of a bucket: x = start << 6 | min(count, 63), y = cell tag of its rank-0 member.  A bucket with ONE member (the
+// common non-empty case) can then be rejected by the query from the descriptor alone when that member belongs to another cell.
+__global__ void k_scatter(long long n_total, const uint32_t* key, const uint32_t* rank, const uint32_t* tag, uint2* cell, uint2* sorted) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_total) return;
   const uint32_t b = key[j];
   if (b == 0xFFFFFFFFu) return;
-  sorted[cell[b].x + rank[j]] = (uint32_t)j;  // (scattering the 48-B records as well was measured 6x slower than this kernel)
+  const uint32_t r = rank[j];
+  sorted[(cell[b].x >> 6) + r] = make_uint2((uint32_t)j, tag[j]);  // (scattering the 48-B records too was measured 6x slower)
+  if (r == 0) cell[b].y = tag[j];
 }
 
 // ---- query ----
@@ -198,16 +214,27 @@ __device__ __forceinline__ bool qualifies(const PosRecord& me, const PosRecord& 
 // index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
 // occupancy; used when the wave-cooperative path below overflows its LDS lists.
 __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask,
-                                  const uint2* cell, const uint32_t* sorted, int crash, double rebounce, double& fx, double& fy, double& fz,
-                                  bool& crashed) {
+                                  const uint2* cell, const uint2* sorted, uint32_t n_entries, int crash, double rebounce, double& fx, double& fy,
+                                  double& fz, bool& crashed) {
   long long prev = -1;
   for (;;) {
     long long best = n_total;
     for (int q = 0; q < 27; q++) {
       const int   cx = c.x + q / 9 - 1, cy = c.y + (q / 3) % 3 - 1, cz = c.z + q % 3 - 1;
-      const uint2 info = cell[bucket_of(cx, cy, cz, mask)];
-      for (uint32_t e = 0; e < info.y; e++) {
-        const long long j = sorted[info.x + e];
+      const uint2    info = cell[bucket_of(cx, cy, cz, mask)];
+      const uint32_t s0 = info.x >> 6;
+      uint32_t       cn = info.x & 63u;
+      if (cn == 63u) {  // saturated count field: walk until the members stop hashing to this bucket
+        cn = 0;
+        while (s0 + cn < n_entries) {  // entries [0, n_entries) were written this tick; slices of different buckets are disjoint
+          const PosRecord t = rec[sorted[s0 + cn].x];
+          const Cell      tc = cell_of(t.x, t.y, t.z);
+          if (!tc.ok || bucket_of(tc.x, tc.y, tc.z, mask) != bucket_of(cx, cy, cz, mask)) break;
+          cn++;
+        }
+      }
+      for (uint32_t e = 0; e < cn; e++) {
+        const long long j = sorted[s0 + e].x;
         if (j <= prev || j >= best || j == gi) continue;
         const PosRecord o  = rec[j];
         const Cell      oc = cell_of(o.x, o.y, o.z);
@@ -233,12 +260,11 @@ constexpr int PAIR_CAP = 1024;
 constexpr int HIT_CAP  = 6;
 
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
-                                              const uint2* cell, const uint32_t* sorted, int crash, double rebounce) {
+                                              const uint2* cell, const uint2* sorted, const uint32_t* n_entries_p, int crash,
+                                              double rebounce) {
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
-  __shared__ uint32_t  pair_j[PAIR_CAP];
-  __shared__ uint8_t   pair_owner[PAIR_CAP];
-  __shared__ int8_t    pair_q[PAIR_CAP];
+  __shared__ uint2     pair_e[PAIR_CAP];  // x: position in `sorted`, y: owner lane | probed cell q << 8
   __shared__ uint32_t  hit_j[64][HIT_CAP];
   __shared__ uint32_t  hit_n[64];
   __shared__ uint32_t  wave_total, overflow;
@@ -258,16 +284,26 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   if (lane == 0) overflow = 0;
 
   // A: descriptors and candidate count.  Unconditional loads from always-valid addresses: a load under a divergent
-  // branch is waited for at the join, which would serialise 27 memory round trips.
+  // branch is waited for at the join, which would serialise 27 memory round trips.  A single-member bucket whose member
+  // carries another cell's tag is dropped right here; members of multi-member buckets are tag-checked in phase C.
   uint2    info[27];
   uint32_t tc = 0;
+  bool     dense = false;  // some probed bucket has a saturated count field
 #pragma unroll
   for (int q = 0; q < 27; q++) info[q] = cell[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
 #pragma unroll
   for (int q = 0; q < 27; q++) {
-    if (!c.ok) info[q] = make_uint2(0u, 0u);
-    tc += info[q].y;
+    uint32_t cn = c.ok ? (info[q].x & 63u) : 0u;
+    if (cn == 1u && info[q].y != cell_tag(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1)) cn = 0u;
+    dense |= (cn == 63u);
+    info[q].y = cn;           // .y now holds the number of candidates taken from this bucket
+    info[q].x = info[q].x >> 6;
+    tc += cn;
   }
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 1
+  if (tc == 0xFFFFFFFFu) sw.F[i] = tc;
+  return;
+#endif
   // B: wave prefix sum -> slots in the pair list; a pair is (owner lane, probed cell q, position in `sorted`)
   uint32_t inc = tc;
 #pragma unroll
@@ -275,13 +311,14 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
     const uint32_t o = __shfl_up(inc, off, 64);
     if (lane >= off) inc += o;
   }
-  if (lane == 63) wave_total = inc;
+  if (lane == 63) wave_total = dense ? 0xFFFFFFFFu : inc;
+  if (dense) overflow = 2;
   __syncthreads();
-  const uint32_t total = wave_total;
+  const uint32_t total = overflow == 2 ? 0xFFFFFFFFu : wave_total;
   if (total > PAIR_CAP) {  // wave-uniform: dense neighbourhood, take the reference path
     double fx = 0, fy = 0, fz = 0;
     bool   crashed = false;
-    if (active && c.ok) query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, crash, rebounce, fx, fy, fz, crashed);
+    if (active && c.ok) query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, *n_entries_p, crash, rebounce, fx, fy, fz, crashed);
     if (active) {
       sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
       sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
@@ -290,57 +327,88 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
     }
     return;
   }
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 4
+  if (total == 0xFFFFFFF0u) sw.F[i] = inc;
+  return;
+#endif
   uint32_t slot = inc - tc;
+  bool     extras = false;
 #pragma unroll
-  for (int q = 0; q < 27; q++) {
+  for (int q = 0; q < 27; q++) {  // branch-light: the first member of every accepted bucket
     const uint32_t cn = info[q].y;
-    for (uint32_t e = 0; e < cn; e++) {  // LDS writes only
-      pair_j[slot]     = info[q].x + e;
-      pair_owner[slot] = (uint8_t)lane;
-      pair_q[slot]     = (int8_t)q;
-      slot++;
+    if (cn) pair_e[slot] = make_uint2(info[q].x, (uint32_t)lane | ((uint32_t)q << 8));
+    slot += cn ? 1u : 0u;
+    extras |= cn > 1u;
+  }
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 5
+  if (slot == 0xFFFFFFF0u) sw.F[i] = pair_e[lane].x;
+  return;
+#endif
+  if (extras) {  // rare: further members of multi-member buckets
+#pragma unroll
+    for (int q = 0; q < 27; q++) {
+      const uint32_t cn = info[q].y;
+      for (uint32_t e = 1; e < cn; e++) pair_e[slot++] = make_uint2(info[q].x + e, (uint32_t)lane | ((uint32_t)q << 8));
     }
   }
   __syncthreads();
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 2
+  if (pair_e[lane].x == 0xFFFFFFFFu) sw.F[i] = 1;
+  return;
+#endif
   // C: uniform sweep over the pairs, four independent pairs per lane and iteration so that their loads overlap
   constexpr int U = 4;
   for (uint32_t base = 0; base < total; base += 64 * U) {
-    uint32_t  pos[U], jj[U];
-    PosRecord o[U];
+    uint2 pe[U], ent[U];
+    bool  live[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + u * 64 + lane;
-      pos[u] = (p < total) ? pair_j[p] : pair_j[0];
+      pe[u] = pair_e[p < total ? p : 0u];
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) jj[u] = sorted[pos[u]];
-#pragma unroll
-    for (int u = 0; u < U; u++) o[u] = rec[jj[u]];
+    for (int u = 0; u < U; u++) ent[u] = sorted[pe[u].x];
+    // tag filter: only members of exactly the probed cell survive (false positives of the 32-bit tag are caught by the exact
+    // cell comparison below)
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + u * 64 + lane;
-      if (p >= total) continue;
-      const int  ow = pair_owner[p], q = pair_q[p];
-      const int4 mc = me_cell[ow];
-      if ((long long)jj[u] == my_offset + blockIdx.x * 64 + ow) continue;  // idx == i, src/multirotor_simulator.cpp:335
-      const Cell oc = cell_of(o[u].x, o[u].y, o[u].z);
-      if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // other cell, same bucket
+      live[u] = false;
+      if (p < total) {
+        const int  ow = (int)(pe[u].y & 0xFFu), q = (int)(pe[u].y >> 8);
+        const int4 mc = me_cell[ow];
+        live[u] = ent[u].y == cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) &&
+                  (long long)ent[u].x != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!live[u]) continue;
+      const int       ow = (int)(pe[u].y & 0xFFu), q = (int)(pe[u].y >> 8);
+      const int4      mc = me_cell[ow];
+      const PosRecord o  = rec[ent[u].x];
+      const Cell      oc = cell_of(o.x, o.y, o.z);
+      if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
       const PosRecord m = me_s[ow];
-      if (!qualifies(m, o[u], crash)) continue;
+      if (!qualifies(m, o, crash)) continue;
       const uint32_t k = atomicAdd(&hit_n[ow], 1u);
       if (k < HIT_CAP)
-        hit_j[ow][k] = jj[u];
+        hit_j[ow][k] = ent[u].x;
       else
         overflow = 1;
     }
   }
   __syncthreads();
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 3
+  if (hit_n[lane] == 0xFFFFFFFFu) sw.F[i] = 1;
+  return;
+#endif
   // D: owners accumulate their hits in ascending partner index
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   if (active && c.ok) {
-    if (overflow && hit_n[lane] > HIT_CAP) {
-      query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, crash, rebounce, fx, fy, fz, crashed);
+    if (overflow == 1 && hit_n[lane] > HIT_CAP) {
+      query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, *n_entries_p, crash, rebounce, fx, fy, fz, crashed);
     } else {
       const uint32_t nh = hit_n[lane];
       uint32_t       prev = 0;
@@ -370,12 +438,12 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 struct CollideWork {
   long long cap_n = 0;
   uint32_t  cap_T = 0;
-  uint32_t *key = nullptr, *rank = nullptr, *sorted = nullptr, *count = nullptr, *cursor = nullptr;
-  uint2*    cell = nullptr;
+  uint32_t *key = nullptr, *rank = nullptr, *tag = nullptr, *count = nullptr, *cursor = nullptr;
+  uint2 *   cell = nullptr, *sorted = nullptr;
 };
 
 static void free_work(CollideWork* w) {
-  (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->cursor);
+  (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->tag); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->cursor);
   (void)hipFree(w->cell);
 }
 
@@ -415,7 +483,8 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
     free_work(w);
     CK(hipMalloc(&w->key, sizeof(uint32_t) * (size_t)n_total));
     CK(hipMalloc(&w->rank, sizeof(uint32_t) * (size_t)n_total));
-    CK(hipMalloc(&w->sorted, sizeof(uint32_t) * (size_t)n_total));
+    CK(hipMalloc(&w->tag, sizeof(uint32_t) * (size_t)n_total));
+    CK(hipMalloc(&w->sorted, sizeof(uint2) * (size_t)n_total));
     CK(hipMalloc(&w->count, sizeof(uint32_t) * (size_t)T));
     CK(hipMalloc(&w->cell, sizeof(uint2) * (size_t)T));
     CK(hipMalloc(&w->cursor, sizeof(uint32_t)));
@@ -427,12 +496,13 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   const uint32_t mask = T - 1;
   const unsigned gN   = (unsigned)((n_total + 255) / 256);
   if (rec_is_local_scratch)
-    hipLaunchKernelGGL(k_pack_hash_count, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, w->key, w->rank, w->count, w->cursor);
+    hipLaunchKernelGGL(k_pack_hash_count, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, w->key, w->rank, w->tag, w->count,
+                       w->cursor);
   else
-    hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->count, w->cursor);
+    hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->tag, w->count, w->cursor);
   hipLaunchKernelGGL(k_alloc_buckets, dim3(T / 1024), dim3(256), 0, st, w->count, w->cell, w->cursor);
-  hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->cell, w->sorted);
-  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, w->cell, w->sorted, crash,
-                     rebounce);
+  hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->tag, w->cell, w->sorted);
+  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, w->cell, w->sorted, w->cursor,
+                     crash, rebounce);
   return hipGetLastError();
 }

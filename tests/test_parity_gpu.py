@@ -517,3 +517,21 @@ def test_concurrent_commands_and_steps(M):
     assert not errors
     st = s.get_state()
     assert np.all(np.isfinite(st["x"])) and np.all(np.abs(st["x"][:, 2] - 12.0) < 3.0)
+
+
+def test_collisions_dense_clusters_take_the_fallback_paths(M, oracle):
+    """More than 63 UAVs in one cell (saturated descriptor count), > 6 qualifying partners per UAV (hit-list overflow) and
+    > 1024 candidate pairs per wavefront: the reference-order fallback must give the same forces / crash flags."""
+    rng = np.random.default_rng(2024)
+    n = 700
+    pos = np.concatenate([rng.uniform(0.0, 0.6, (200, 3)) + [5, 5, 5],          # 200 UAVs inside one 1.75 m cell
+                          rng.uniform(0.0, 3.0, (300, 3)) + [20, 20, 20],        # dense blob over a few cells
+                          rng.uniform(-30, 30, (200, 3))])                       # background
+    for crash in (False, True):
+        p = Pair(M, n)
+        p.construct(0, n, "x500", pos=pos, heading=np.zeros(n))
+        p.both("handle_collisions", True, crash, 100.0)
+        assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
+        helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "dense forces")
+        if not crash:
+            assert (np.abs(p.o.get_external_force()).sum(axis=1) > 0).sum() > 400
