@@ -535,3 +535,23 @@ def test_collisions_dense_clusters_take_the_fallback_paths(M, oracle):
         helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "dense forces")
         if not crash:
             assert (np.abs(p.o.get_external_force()).sum(axis=1) > 0).sum() > 400
+
+
+def test_full_size_100k_collision_tick_against_oracle(M, oracle):
+    """BASELINE config 4 at its full size: 100 000 UAVs at 64 m^3 per UAV, elastic collisions.  Whole-swarm comparison of
+    the forces with the oracle plus the size-independent property that equal-mass pair forces cancel (sum F = 0)."""
+    rng = np.random.default_rng(4)
+    n = 100_000
+    side = (64.0 * n) ** (1.0 / 3.0)
+    pos = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
+    pos[:2000] = pos[2000:4000] + rng.normal(0, 0.3, (2000, 3))  # make sure a few thousand pairs really touch
+    p = Pair(M, n)
+    p.construct(0, n, "x500", pos=pos, heading=np.zeros(n))
+    p.both("handle_collisions", True, False, 100.0)
+    fg, fo = p.g.get_external_force(), p.o.get_external_force()
+    touched = (np.abs(fo).sum(axis=1) > 0).sum()
+    assert touched > 2000
+    helpers.assert_close(fg, fo, 1e-13, "forces at 100k")
+    assert np.abs(fg.sum(axis=0)).max() < 1e-9 * np.abs(fg).sum()
+    p.both("handle_collisions", False, True, 100.0)
+    assert np.array_equal(p.g.has_crashed(), p.o.has_crashed()) and p.o.has_crashed().sum() == touched
