@@ -11,17 +11,14 @@
 // Only the neighbour *set* of the kd-tree matters; forces are summed in ascending partner index (the kd-tree's
 // traversal order is not reproducible by any other structure; with <= 1 partner, the usual case, the sum is exact).
 //
-// Pipeline per tick (all on the swarm's stream, HBM-bound integer/index work):
-//   pack      : SoA state + type table -> 48-B PosRecord per UAV (the multi-GPU all-gather payload; fused with
-//               hash_count on a single GPU)
-//   hash_count: cell = floor(pos / 1.75 m) (> sqrt(3), so partners sit in the 27 adjacent cells);
-//               bucket = hash(cell) & (T-1); rank = atomicAdd(count[bucket])
-//   alloc     : every 1024-bucket block scans its counts and reserves its slice of `sorted` with one atomicAdd
-//               (buckets need disjoint slices, not ordered ones); writes {start,count} per bucket, re-zeroes count[]
-//   scatter   : sorted[start[bucket] + rank] = j
-//   query     : one lane per local UAV fetches the 27 bucket descriptors, walks the non-empty ones with an exact cell
-//               match (dedupes buckets shared by several cells) and the literal predicate; partners are consumed in
-//               ascending index, which makes the result independent of the atomic arrival order
+// Pipeline per tick (all on the swarm's stream, HBM-bound integer/index work) — two kernels:
+//   insert : SoA state + type table -> 48-B PosRecord per UAV (the multi-GPU all-gather payload; gathered records skip the
+//            packing); cell = floor(pos / 1.75 m) (> sqrt(3), so partners sit in the 27 adjacent cells);
+//            bucket = hash(cell) & (T-1); the UAV becomes the head of its bucket's chain with ONE 64-bit atomic exchange and
+//            keeps the previous head as its `next` link.  No counting pass, no prefix sum, no scatter.
+//   query  : one single-wave workgroup per 64 local UAVs fetches the 27 bucket heads per lane, follows the (rare) chains and
+//            evaluates the literal predicate; partners are consumed in ascending index, which makes the result
+//            independent of the atomic arrival order.  It also clears the OTHER head table for the next tick.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,8 +51,6 @@ __device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t m
   return (h + (uint32_t)cz) & mask;
 }
 
-// second, independent hash of the exact cell: stored next to every index in `sorted`, it lets the query discard the members of
-// OTHER cells that share a bucket (about 5 per UAV at load factor 0.19) without fetching their 48-B records
 __device__ __forceinline__ uint32_t cell_tag(int cx, int cy, int cz) {
   uint32_t h = (uint32_t)cx * 0x9E3779B1u + (uint32_t)cy * 0x85EBCA77u + (uint32_t)cz * 0xC2B2AE3Du;
   h ^= h >> 16;
@@ -81,27 +76,36 @@ __global__ void k_pack_positions(SwarmDev sw, PosRecord* out) {
   out[i] = r;
 }
 
-__global__ void k_hash_count(const PosRecord* rec, long long n_total, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* tag,
-                             uint32_t* count, uint32_t* cursor) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) *cursor = 0;  // the allocation cursor of this tick (k_alloc_buckets runs after this kernel)
-  if (j >= n_total) return;
-  const Cell c = cell_of(rec[j].x, rec[j].y, rec[j].z);
-  if (!c.ok) {
-    key[j] = 0xFFFFFFFFu;  // never inserted
+// Head / link word: x = UAV index + 1 (0 = empty / end of chain), y = cell tag (31 bits) | CHAIN bit.
+// The tag is a second, independent hash of the exact cell: it lets the query discard members of OTHER cells that share a
+// bucket (about 5 probes per UAV at load factor 0.25) without fetching their 48-B records.  CHAIN on a bucket head says
+// "more than one member": a single-member bucket is accepted or dropped from its head word alone.
+constexpr uint32_t CHAIN_BIT = 0x80000000u;
+
+__device__ __forceinline__ void insert_uav(long long j, const Cell& c, uint32_t mask, uint2* head, uint2* next) {
+  if (!c.ok) {  // never inserted
+    next[j] = make_uint2(0u, 0u);
     return;
   }
   const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
-  key[j]  = b;
-  tag[j]  = cell_tag(c.x, c.y, c.z);
-  rank[j] = atomicAdd(&count[b], 1u);
+  const unsigned long long me = (unsigned long long)((uint32_t)j + 1u) | ((unsigned long long)(cell_tag(c.x, c.y, c.z) & ~CHAIN_BIT) << 32);
+  unsigned long long* slot = reinterpret_cast<unsigned long long*>(head + b);
+  const unsigned long long old = atomicExch(slot, me);
+  next[j] = make_uint2((uint32_t)old, (uint32_t)(old >> 32) & ~CHAIN_BIT);
+  // Whoever finds the bucket occupied marks it as a chain.  The mark is only ever set, and the thread whose exchange comes
+  // last is not the first member, so it sets the bit after its own exchange: the final head carries it iff members > 1.
+  if ((uint32_t)old != 0u) atomicOr(slot, (unsigned long long)CHAIN_BIT << 32);
 }
 
-// single-GPU tick: pack and hash in one pass over the state (the records are still written: the query reads them)
-__global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, uint32_t* key, uint32_t* rank, uint32_t* tag,
-                                  uint32_t* count, uint32_t* cursor) {
+__global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask, uint2* head, uint2* next) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_total) return;
+  insert_uav(j, cell_of(rec[j].x, rec[j].y, rec[j].z), mask, head, next);
+}
+
+// single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them)
+__global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *cursor = 0;
   if (i >= sw.n) return;
   const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
   PosRecord r;
@@ -112,67 +116,7 @@ __global__ void k_pack_hash_count(SwarmDev sw, PosRecord* rec, uint32_t mask, ui
   r.arm_length  = P.arm_length;
   r.prop_radius = P.prop_radius;
   rec[i] = r;
-  const Cell c = cell_of(r.x, r.y, r.z);
-  if (!c.ok) {
-    key[i] = 0xFFFFFFFFu;
-    return;
-  }
-  const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
-  key[i]  = b;
-  tag[i]  = cell_tag(c.x, c.y, c.z);
-  rank[i] = atomicAdd(&count[b], 1u);
-}
-
-// ---- bucket storage allocation: one kernel instead of a full prefix sum ----
-// Buckets need disjoint slices of `sorted`, not slices in bucket order: each 1024-bucket block scans its own counts
-// in registers/LDS and reserves its total with ONE atomicAdd on a global cursor.  Writes start<<6|count per bucket and
-// re-zeroes count[] for the next tick (this kernel is its last reader).
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wsum[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t  inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
-  if (lane == 63) wsum[wv] = inc;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int q = 0; q < wv; q++) base += wsum[q];
-  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  return base + inc - v;
-}
-
-__global__ void __launch_bounds__(256) k_alloc_buckets(uint32_t* count, uint2* cell, uint32_t* cursor) {
-  __shared__ uint32_t block_base;
-  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const uint4  c = reinterpret_cast<const uint4*>(count)[q];
-  uint32_t     total;
-  const uint32_t ex = block_excl_scan_256(c.x + c.y + c.z + c.w, &total);
-  if (threadIdx.x == 0) block_base = total ? atomicAdd(cursor, total) : 0u;
-  __syncthreads();
-  const uint32_t s0 = block_base + ex;
-  uint2* o = cell + q * 4;
-#define MRS_DESC(start, cnt) make_uint2(((start) << 6) | ((cnt) < 63u ? (cnt) : 63u), 0u)
-  o[0] = MRS_DESC(s0, c.x);
-  o[1] = MRS_DESC(s0 + c.x, c.y);
-  o[2] = MRS_DESC(s0 + c.x + c.y, c.z);
-  o[3] = MRS_DESC(s0 + c.x + c.y + c.z, c.w);
-#undef MRS_DESC
-  reinterpret_cast<uint4*>(count)[q] = make_uint4(0, 0, 0, 0);
-}
-
-// Descriptor of a bucket: x = start << 6 | min(count, 63), y = cell tag of its rank-0 member.  A bucket with ONE member (the
-// common non-empty case) can then be rejected by the query from the descriptor alone when that member belongs to another cell.
-__global__ void k_scatter(long long n_total, const uint32_t* key, const uint32_t* rank, const uint32_t* tag, uint2* cell, uint2* sorted) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_total) return;
-  const uint32_t b = key[j];
-  if (b == 0xFFFFFFFFu) return;
-  const uint32_t r = rank[j];
-  sorted[(cell[b].x >> 6) + r] = make_uint2((uint32_t)j, tag[j]);  // (scattering the 48-B records too was measured 6x slower)
-  if (r == 0) cell[b].y = tag[j];
+  insert_uav(i, cell_of(r.x, r.y, r.z), mask, head, next);
 }
 
 // ---- query ----
@@ -210,35 +154,24 @@ __device__ __forceinline__ bool qualifies(const PosRecord& me, const PosRecord& 
   return dist < crit_ij || (crash && dist < crit_ji);
 }
 
-// reference path for one lane: repeated sweeps over the 27 buckets, each returning the smallest qualifying partner
+// reference path for one lane: repeated sweeps over the 27 bucket chains, each returning the smallest qualifying partner
 // index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
 // occupancy; used when the wave-cooperative path below overflows its LDS lists.
 __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask,
-                                  const uint2* cell, const uint2* sorted, uint32_t n_entries, int crash, double rebounce, double& fx, double& fy,
-                                  double& fz, bool& crashed) {
+                                  const uint2* head, const uint2* next, int crash, double rebounce, double& fx, double& fy, double& fz,
+                                  bool& crashed) {
   long long prev = -1;
   for (;;) {
     long long best = n_total;
     for (int q = 0; q < 27; q++) {
-      const int   cx = c.x + q / 9 - 1, cy = c.y + (q / 3) % 3 - 1, cz = c.z + q % 3 - 1;
-      const uint2    info = cell[bucket_of(cx, cy, cz, mask)];
-      const uint32_t s0 = info.x >> 6;
-      uint32_t       cn = info.x & 63u;
-      if (cn == 63u) {  // saturated count field: walk until the members stop hashing to this bucket
-        cn = 0;
-        while (s0 + cn < n_entries) {  // entries [0, n_entries) were written this tick; slices of different buckets are disjoint
-          const PosRecord t = rec[sorted[s0 + cn].x];
-          const Cell      tc = cell_of(t.x, t.y, t.z);
-          if (!tc.ok || bucket_of(tc.x, tc.y, tc.z, mask) != bucket_of(cx, cy, cz, mask)) break;
-          cn++;
-        }
-      }
-      for (uint32_t e = 0; e < cn; e++) {
-        const long long j = sorted[s0 + e].x;
-        if (j <= prev || j >= best || j == gi) continue;
+      const int      cx = c.x + q / 9 - 1, cy = c.y + (q / 3) % 3 - 1, cz = c.z + q % 3 - 1;
+      const uint32_t tg = cell_tag(cx, cy, cz) & ~CHAIN_BIT;
+      for (uint2 e = head[bucket_of(cx, cy, cz, mask)]; e.x != 0u; e = next[e.x - 1u]) {
+        const long long j = (long long)e.x - 1;
+        if ((e.y & ~CHAIN_BIT) != tg || j <= prev || j >= best || j == gi) continue;
         const PosRecord o  = rec[j];
         const Cell      oc = cell_of(o.x, o.y, o.z);
-        if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // another cell sharing the bucket
+        if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // another cell sharing the bucket (and the tag)
         if (qualifies(me, o, crash)) best = j;
       }
     }
@@ -249,25 +182,28 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
 }
 
 // Wave-cooperative query, one single-wave workgroup per 64 local UAVs.
-//   A  every lane fetches its 27 bucket descriptors and the first entry of each non-empty bucket (independent loads,
-//      one memory round trip), and counts its candidates (~2 on a 64 m^3/UAV swarm: nearly all buckets are empty)
-//   B  the (owner lane, candidate) pairs of the whole wave are compacted into an LDS list (wave prefix sum)
-//   C  the list is processed 64 pairs at a time with uniform control flow — this is what removes the 27-way divergent
-//      walk in which some lane always had a non-empty bucket and every iteration paid a full memory latency;
-//      qualifying partners go to a small per-owner hit list (LDS atomics)
+//   A  every lane fetches its 27 bucket heads (independent loads, one memory round trip); a head whose tag is not the probed
+//      cell's and that has no chain is dropped on the spot (~2 candidates per UAV remain on a 64 m^3/UAV swarm)
+//   B  the (owner lane, probed cell, candidate) triples of the whole wave are compacted into an LDS list (wave prefix sum)
+//   C  the list is processed 64 x U entries at a time with uniform control flow — this is what removes the 27-way divergent
+//      walk in which some lane always had a non-empty bucket and every iteration paid a full memory latency.  An entry
+//      of a chained bucket also fetches its `next` link and appends it to the list; qualifying partners go to a small
+//      per-owner hit list (LDS atomics)
 //   D  owners order their (rare) hits by index and accumulate; overflow of either list falls back to query_lane_sweeps
-constexpr int PAIR_CAP = 1024;
-constexpr int HIT_CAP  = 6;
+constexpr int      PAIR_CAP  = 1024;
+constexpr int      HIT_CAP   = 6;
+constexpr uint32_t META_WALK = 0x10000u;  // pair meta: owner lane | probed cell q << 8 | WALK (follow the `next` link)
 
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
-                                              const uint2* cell, const uint2* sorted, const uint32_t* n_entries_p, int crash,
+                                              const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
                                               double rebounce) {
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
-  __shared__ uint2     pair_e[PAIR_CAP];  // x: position in `sorted`, y: owner lane | probed cell q << 8
+  __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag
+  __shared__ uint32_t  pair_m[PAIR_CAP];   // meta
   __shared__ uint32_t  hit_j[64][HIT_CAP];
   __shared__ uint32_t  hit_n[64];
-  __shared__ uint32_t  wave_total, overflow;
+  __shared__ uint32_t  list_total, list_overflow, hit_overflow;  // two flags: each is only ever set, never downgraded
 
   const int       lane   = threadIdx.x;
   const int       i      = blockIdx.x * 64 + lane;
@@ -281,74 +217,51 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   me_s[lane]   = me;
   me_cell[lane] = make_int4(c.x, c.y, c.z, 0);
   hit_n[lane]  = 0;
-  if (lane == 0) overflow = 0;
+  if (lane == 0) list_overflow = hit_overflow = 0;
 
-  // A: descriptors and candidate count.  Unconditional loads from always-valid addresses: a load under a divergent
-  // branch is waited for at the join, which would serialise 27 memory round trips.  A single-member bucket whose member
-  // carries another cell's tag is dropped right here; members of multi-member buckets are tag-checked in phase C.
+  // A: bucket heads.  Unconditional loads from always-valid addresses: a load under a divergent branch is waited for at
+  // the join, which would serialise 27 memory round trips.
   uint2    info[27];
   uint32_t tc = 0;
-  bool     dense = false;  // some probed bucket has a saturated count field
 #pragma unroll
-  for (int q = 0; q < 27; q++) info[q] = cell[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
+  for (int q = 0; q < 27; q++) info[q] = head[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
+  // this tick's table has been read: wipe the other one for the next tick (grid-strided, coalesced)
+  {
+    const uint32_t stride = gridDim.x * 64u;
+    for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
+  }
 #pragma unroll
   for (int q = 0; q < 27; q++) {
-    uint32_t cn = c.ok ? (info[q].x & 63u) : 0u;
-    if (cn == 1u && info[q].y != cell_tag(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1)) cn = 0u;
-    dense |= (cn == 63u);
-    info[q].y = cn;           // .y now holds the number of candidates taken from this bucket
-    info[q].x = info[q].x >> 6;
-    tc += cn;
+    const uint32_t tg    = cell_tag(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1) & ~CHAIN_BIT;
+    const bool     chain = (info[q].y & CHAIN_BIT) != 0u;
+    const bool     take  = c.ok && info[q].x != 0u && (chain || info[q].y == tg);
+    info[q].y = (info[q].y & ~CHAIN_BIT);
+    if (!take) info[q].x = 0u;
+    // .x != 0: entry goes to the list;  keep the chain flag in the top bit of .y again for phase B
+    if (take && chain) info[q].y |= CHAIN_BIT;
+    tc += take ? 1u : 0u;
   }
 #if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 1
   if (tc == 0xFFFFFFFFu) sw.F[i] = tc;
   return;
 #endif
-  // B: wave prefix sum -> slots in the pair list; a pair is (owner lane, probed cell q, position in `sorted`)
+  // B: wave prefix sum -> slots in the pair list
   uint32_t inc = tc;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t o = __shfl_up(inc, off, 64);
     if (lane >= off) inc += o;
   }
-  if (lane == 63) wave_total = dense ? 0xFFFFFFFFu : inc;
-  if (dense) overflow = 2;
-  __syncthreads();
-  const uint32_t total = overflow == 2 ? 0xFFFFFFFFu : wave_total;
-  if (total > PAIR_CAP) {  // wave-uniform: dense neighbourhood, take the reference path
-    double fx = 0, fy = 0, fz = 0;
-    bool   crashed = false;
-    if (active && c.ok) query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, *n_entries_p, crash, rebounce, fx, fy, fz, crashed);
-    if (active) {
-      sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
-      sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
-      sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
-      if (crashed) sw.F[i] |= FLAG_CRASHED;
-    }
-    return;
-  }
-#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 4
-  if (total == 0xFFFFFFF0u) sw.F[i] = inc;
-  return;
-#endif
+  if (lane == 63) list_total = inc;
   uint32_t slot = inc - tc;
-  bool     extras = false;
 #pragma unroll
-  for (int q = 0; q < 27; q++) {  // branch-light: the first member of every accepted bucket
-    const uint32_t cn = info[q].y;
-    if (cn) pair_e[slot] = make_uint2(info[q].x, (uint32_t)lane | ((uint32_t)q << 8));
-    slot += cn ? 1u : 0u;
-    extras |= cn > 1u;
-  }
-#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 5
-  if (slot == 0xFFFFFFF0u) sw.F[i] = pair_e[lane].x;
-  return;
-#endif
-  if (extras) {  // rare: further members of multi-member buckets
-#pragma unroll
-    for (int q = 0; q < 27; q++) {
-      const uint32_t cn = info[q].y;
-      for (uint32_t e = 1; e < cn; e++) pair_e[slot++] = make_uint2(info[q].x + e, (uint32_t)lane | ((uint32_t)q << 8));
+  for (int q = 0; q < 27; q++) {
+    if (info[q].x != 0u) {
+      if (slot < (uint32_t)PAIR_CAP) {  // 64 x 27 heads can exceed the list: the total is checked below
+        pair_e[slot] = make_uint2(info[q].x, info[q].y & ~CHAIN_BIT);
+        pair_m[slot] = (uint32_t)lane | ((uint32_t)q << 8) | ((info[q].y & CHAIN_BIT) ? META_WALK : 0u);
+      }
+      slot++;
     }
   }
   __syncthreads();
@@ -356,47 +269,68 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   if (pair_e[lane].x == 0xFFFFFFFFu) sw.F[i] = 1;
   return;
 #endif
-  // C: uniform sweep over the pairs, four independent pairs per lane and iteration so that their loads overlap
+  // C: uniform sweep over the list, U independent entries per lane and iteration so that their loads overlap
   constexpr int U = 4;
-  for (uint32_t base = 0; base < total; base += 64 * U) {
-    uint2 pe[U], ent[U];
-    bool  live[U];
+  uint32_t total = list_total;
+  if (total > PAIR_CAP) {
+    list_overflow = 1;
+    total         = 0;
+  }
+  for (uint32_t base = 0; base < total;) {
+    uint2    pe[U], nx[U];
+    uint32_t pm[U];
+    bool     live[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + u * 64 + lane;
       pe[u] = pair_e[p < total ? p : 0u];
+      pm[u] = p < total ? pair_m[p] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) ent[u] = sorted[pe[u].x];
-    // tag filter: only members of exactly the probed cell survive (false positives of the 32-bit tag are caught by the exact
+    for (int u = 0; u < U; u++) nx[u] = (pm[u] & META_WALK) ? next[pe[u].x - 1u] : make_uint2(0u, 0u);
+    // tag filter: only members of exactly the probed cell survive (false positives of the 31-bit tag are caught by the exact
     // cell comparison below)
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t p = base + u * 64 + lane;
       live[u] = false;
       if (p < total) {
-        const int  ow = (int)(pe[u].y & 0xFFu), q = (int)(pe[u].y >> 8);
+        const int  ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
         const int4 mc = me_cell[ow];
-        live[u] = ent[u].y == cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) &&
-                  (long long)ent[u].x != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
+        live[u] = pe[u].y == (cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) & ~CHAIN_BIT) &&
+                  (long long)pe[u].x - 1 != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
       }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
+      if (nx[u].x != 0u) {  // the chain goes on: its next member joins the list
+        const uint32_t k = atomicAdd(&list_total, 1u);
+        if (k < PAIR_CAP) {
+          pair_e[k] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
+          pair_m[k] = pm[u];
+        } else {
+          list_overflow = 1;
+        }
+      }
       if (!live[u]) continue;
-      const int       ow = (int)(pe[u].y & 0xFFu), q = (int)(pe[u].y >> 8);
+      const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
       const int4      mc = me_cell[ow];
-      const PosRecord o  = rec[ent[u].x];
+      const PosRecord o  = rec[pe[u].x - 1u];
       const Cell      oc = cell_of(o.x, o.y, o.z);
       if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
       const PosRecord m = me_s[ow];
       if (!qualifies(m, o, crash)) continue;
       const uint32_t k = atomicAdd(&hit_n[ow], 1u);
       if (k < HIT_CAP)
-        hit_j[ow][k] = ent[u].x;
+        hit_j[ow][k] = pe[u].x - 1u;
       else
-        overflow = 1;
+        hit_overflow = 1;
     }
+    base = (base + 64 * U < total) ? base + 64 * U : total;  // entries appended meanwhile start at the old total
+    __syncthreads();  // appended entries and the new total are visible
+    total = list_total;
+    if (list_overflow) total = 0;
+    __syncthreads();  // nobody appends before everybody has read the total
   }
   __syncthreads();
 #if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 3
@@ -407,8 +341,8 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   if (active && c.ok) {
-    if (overflow == 1 && hit_n[lane] > HIT_CAP) {
-      query_lane_sweeps(me, c, gi, rec, n_total, mask, cell, sorted, *n_entries_p, crash, rebounce, fx, fy, fz, crashed);
+    if (list_overflow || (hit_overflow && hit_n[lane] > HIT_CAP)) {  // dense neighbourhood: the reference path
+      query_lane_sweeps(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
     } else {
       const uint32_t nh = hit_n[lane];
       uint32_t       prev = 0;
@@ -438,13 +372,13 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 struct CollideWork {
   long long cap_n = 0;
   uint32_t  cap_T = 0;
-  uint32_t *key = nullptr, *rank = nullptr, *tag = nullptr, *count = nullptr, *cursor = nullptr;
-  uint2 *   cell = nullptr, *sorted = nullptr;
+  int       cur   = 0;  // which head table the next tick fills; the other one is being wiped by that tick's query
+  uint2 *   head[2] = {nullptr, nullptr}, *next = nullptr;
 };
 
 static void free_work(CollideWork* w) {
-  (void)hipFree(w->key); (void)hipFree(w->rank); (void)hipFree(w->tag); (void)hipFree(w->sorted); (void)hipFree(w->count); (void)hipFree(w->cursor);
-  (void)hipFree(w->cell);
+  (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
+  w->head[0] = w->head[1] = w->next = nullptr;
 }
 
 extern "C" void mrs_collide_free(CollideWork* w) {
@@ -481,28 +415,28 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   if (n_total > w->cap_n || T > w->cap_T) {
     CK(hipStreamSynchronize(st));
     free_work(w);
-    CK(hipMalloc(&w->key, sizeof(uint32_t) * (size_t)n_total));
-    CK(hipMalloc(&w->rank, sizeof(uint32_t) * (size_t)n_total));
-    CK(hipMalloc(&w->tag, sizeof(uint32_t) * (size_t)n_total));
-    CK(hipMalloc(&w->sorted, sizeof(uint2) * (size_t)n_total));
-    CK(hipMalloc(&w->count, sizeof(uint32_t) * (size_t)T));
-    CK(hipMalloc(&w->cell, sizeof(uint2) * (size_t)T));
-    CK(hipMalloc(&w->cursor, sizeof(uint32_t)));
-    CK(hipMemsetAsync(w->count, 0, sizeof(uint32_t) * (size_t)T, st));  // k_alloc_buckets re-zeroes it after every use
+    CK(hipMalloc(&w->head[0], sizeof(uint2) * (size_t)T));
+    CK(hipMalloc(&w->head[1], sizeof(uint2) * (size_t)T));
+    CK(hipMalloc(&w->next, sizeof(uint2) * (size_t)n_total));
+    CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * (size_t)T, st));  // afterwards every query wipes the table of the next tick
+    CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * (size_t)T, st));
     w->cap_n = n_total;
     w->cap_T = T;
+    w->cur   = 0;
   }
-  T = w->cap_T;  // a larger table from an earlier call is still valid (count[] is all zero between ticks)
+  T = w->cap_T;  // a larger table from an earlier call is still valid (both tables are empty between ticks)
   const uint32_t mask = T - 1;
   const unsigned gN   = (unsigned)((n_total + 255) / 256);
+  uint2*         head = w->head[w->cur];
+  uint2*         other = w->head[w->cur ^ 1];
+  w->cur ^= 1;
   if (rec_is_local_scratch)
-    hipLaunchKernelGGL(k_pack_hash_count, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, w->key, w->rank, w->tag, w->count,
-                       w->cursor);
+    hipLaunchKernelGGL(k_pack_insert, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next);
   else
-    hipLaunchKernelGGL(k_hash_count, dim3(gN), dim3(256), 0, st, rec, n_total, mask, w->key, w->rank, w->tag, w->count, w->cursor);
-  hipLaunchKernelGGL(k_alloc_buckets, dim3(T / 1024), dim3(256), 0, st, w->count, w->cell, w->cursor);
-  hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(256), 0, st, n_total, w->key, w->rank, w->tag, w->cell, w->sorted);
-  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, w->cell, w->sorted, w->cursor,
-                     crash, rebounce);
+    hipLaunchKernelGGL(k_insert, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
+  // `other` was wiped by the previous query except for what that query's own tick left in it: nothing — it is the table of
+  // two ticks ago, wiped one tick ago.  This tick's table is wiped by the NEXT query; the very first tick starts from memset.
+  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
+                     rebounce);
   return hipGetLastError();
 }
