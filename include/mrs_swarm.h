@@ -195,6 +195,11 @@ int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst);
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,
                                          int32_t enabled, int32_t crash, double rebounce);
 
+/* collision-pass statistics of mrs_swarm_handle_collisions / mrs_swarm_tick_n: ticks that ran the pass, and how many of them had to
+ * repeat the neighbour search (the others reused the neighbour lists of an earlier tick — same results as the reference's per-tick
+ * kd-tree, src/multirotor_simulator.cpp:303-317, which this replaces) */
+int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds);
+
 /* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
  * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
  * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */

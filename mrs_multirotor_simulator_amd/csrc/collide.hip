@@ -19,6 +19,16 @@
 //   query  : one single-wave workgroup per 64 local UAVs fetches the 27 bucket heads per lane, follows the (rare) chains and
 //            evaluates the literal predicate; partners are consumed in ascending index, which makes the result
 //            independent of the atomic arrival order.  It also clears the OTHER head table for the next tick.
+//
+// Neighbour lists (single-GPU ticks): UAVs move centimetres per tick, so the partner search above is only REPEATED when it
+// has to be.  A rebuild tick runs insert + query with 2.25-m cells and keeps, per UAV, the ascending list of every UAV
+// within sqrt(3) + SKIN of it, together with the positions at that moment.  The step kernel compares every new position
+// with the recorded one (step_device.inc) and raises a flag once any UAV has moved more than SKIN/2; until then a pair
+// closer than sqrt(3) now was closer than sqrt(3) + SKIN at the rebuild, i.e. is in the lists, and a tick is ONE cheap
+// pass: current positions of the listed UAVs -> literal predicate -> forces / crash flags, in the same ascending order.
+// The decision is taken on the device (both kernels are always launched; insert returns at once on a list tick), host
+// writes to positions or airframe constants force a rebuild, and a UAV with more than LIST_CAP listed neighbours keeps
+// the pass in rebuild mode.  Results are identical to searching every tick.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,18 +36,25 @@
 
 namespace {
 
-constexpr double INV_CELL  = 1.0 / 1.75; // cell edge 1.75 m > sqrt(3.0) = 1.7320508; // cells are floor(pos * INV_CELL): any consistent assignment with edge > sqrt(3) works,
-                                         // and the multiply avoids three ~70-cycle IEEE divisions per cell_of
-constexpr double POS_LIMIT = 1.0e9;      // |coordinate| beyond this (or non-finite) never collides here
+// cells are floor(pos * INV_CELL): any consistent assignment with an edge above the search radius works, and the multiply
+// avoids three ~70-cycle IEEE divisions per cell_of
+constexpr double INV_CELL      = 1.0 / 1.75;  // plain search: edge 1.75 m > sqrt(3.0) = 1.7320508
+constexpr double SKIN          = 0.5;         // neighbour lists: how far apart beyond sqrt(3) a listed pair may be
+constexpr double INV_CELL_WIDE = 1.0 / 2.25;  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508
+constexpr double LIST_R2       = 4.9821;      // > (sqrt(3) + SKIN)^2 = 4.98205...
+constexpr double POS_LIMIT     = 1.0e9;       // |coordinate| beyond this (or non-finite) never collides here
+constexpr int    LIST_CAP      = 8;           // listed neighbours per UAV (0.7 expected at 64 m^3 per UAV)
 
 struct Cell { int x, y, z; bool ok; };
 
+template <bool WIDE>
 __device__ __forceinline__ Cell cell_of(double x, double y, double z) {
+  constexpr double ic = WIDE ? INV_CELL_WIDE : INV_CELL;
   Cell c;
   c.ok = (fabs(x) < POS_LIMIT) && (fabs(y) < POS_LIMIT) && (fabs(z) < POS_LIMIT);  // false for NaN/inf
-  c.x  = c.ok ? (int)floor(x * INV_CELL) : 0;
-  c.y  = c.ok ? (int)floor(y * INV_CELL) : 0;
-  c.z  = c.ok ? (int)floor(z * INV_CELL) : 0;
+  c.x  = c.ok ? (int)floor(x * ic) : 0;
+  c.y  = c.ok ? (int)floor(y * ic) : 0;
+  c.z  = c.ok ? (int)floor(z * ic) : 0;
   return c;
 }
 
@@ -97,15 +114,29 @@ __device__ __forceinline__ void insert_uav(long long j, const Cell& c, uint32_t 
   if ((uint32_t)old != 0u) atomicOr(slot, (unsigned long long)CHAIN_BIT << 32);
 }
 
+// ctl[0], ctl[1]: "some UAV has left its skin" flags of alternating ticks (written by the step kernel), see the header
+template <bool LISTS>
 __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask, uint2* head, uint2* next) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_total) return;
-  insert_uav(j, cell_of(rec[j].x, rec[j].y, rec[j].z), mask, head, next);
+  insert_uav(j, cell_of<LISTS>(rec[j].x, rec[j].y, rec[j].z), mask, head, next);
 }
 
-// single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them)
-__global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next) {
+// single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them).
+// With LISTS the pass only happens on a rebuild tick; the records then double as the reference positions of the skin test.
+template <bool LISTS>
+__global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
+                              int table_id) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (LISTS) {
+    const bool rebuild = force || ctl[cur] != 0u;
+    if (i == 0) {
+      ctl[cur ^ 1]     = 0u;  // the next tick's flag: the step kernel (or this tick's query, on list overflow) raises it
+      ctl[4 + table_id] = rebuild ? 1u : 0u;  // "this head table holds entries": the next tick's query wipes it if so
+      if (rebuild) ctl[2] += 1u;              // statistics: number of rebuild ticks
+    }
+    if (!rebuild) return;
+  }
   if (i >= sw.n) return;
   const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
   PosRecord r;
@@ -116,7 +147,7 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   r.arm_length  = P.arm_length;
   r.prop_radius = P.prop_radius;
   rec[i] = r;
-  insert_uav(i, cell_of(r.x, r.y, r.z), mask, head, next);
+  insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
 // ---- query ----
@@ -157,6 +188,7 @@ __device__ __forceinline__ bool qualifies(const PosRecord& me, const PosRecord& 
 // reference path for one lane: repeated sweeps over the 27 bucket chains, each returning the smallest qualifying partner
 // index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
 // occupancy; used when the wave-cooperative path below overflows its LDS lists.
+template <bool WIDE>
 __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask,
                                   const uint2* head, const uint2* next, int crash, double rebounce, double& fx, double& fy, double& fz,
                                   bool& crashed) {
@@ -170,7 +202,7 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
         const long long j = (long long)e.x - 1;
         if ((e.y & ~CHAIN_BIT) != tg || j <= prev || j >= best || j == gi) continue;
         const PosRecord o  = rec[j];
-        const Cell      oc = cell_of(o.x, o.y, o.z);
+        const Cell      oc = cell_of<WIDE>(o.x, o.y, o.z);
         if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // another cell sharing the bucket (and the tag)
         if (qualifies(me, o, crash)) best = j;
       }
@@ -190,13 +222,61 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
 //      of a chained bucket also fetches its `next` link and appends it to the list; qualifying partners go to a small
 //      per-owner hit list (LDS atomics)
 //   D  owners order their (rare) hits by index and accumulate; overflow of either list falls back to query_lane_sweeps
+#ifndef MRS_TABLE_FACTOR
+#define MRS_TABLE_FACTOR 4
+#endif
 constexpr int      PAIR_CAP  = 1024;
 constexpr int      HIT_CAP   = 6;
 constexpr uint32_t META_WALK = 0x10000u;  // pair meta: owner lane | probed cell q << 8 | WALK (follow the `next` link)
 
+#ifdef MRS_QUERY_CLOCK
+// constant-clock timestamp that cannot be scheduled before `dep` is available, nor across memory operations
+__device__ __forceinline__ unsigned long long clock_fence(uint32_t dep) {
+  unsigned long long t;
+  asm volatile("v_readfirstlane_b32 s4, %1\n s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory", "s4");
+  return t;
+}
+#endif
+
+// One tick from the neighbour lists: current positions of the listed UAVs, literal predicate, ascending partner index.
+// Most UAVs have nobody listed: they only read their count and write the zero force (applyForce runs for every UAV, :356-358).
+__device__ __forceinline__ PosRecord current_record(const SwarmDev& sw, const PosRecord* rec, uint32_t j) {
+  const size_t np = (size_t)sw.npad;
+  PosRecord    o  = rec[j];  // airframe constants; the position is the CURRENT one
+  o.x = sw.S[(size_t)(F_X + 0) * np + j];
+  o.y = sw.S[(size_t)(F_X + 1) * np + j];
+  o.z = sw.S[(size_t)(F_X + 2) * np + j];
+  return o;
+}
+
+__device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* rec, const uint32_t* nbr, const uint32_t* nbr_cnt, int i, int crash,
+                                          double rebounce) {
+  const size_t   np  = (size_t)sw.npad;
+  const uint32_t cnt = nbr_cnt[i];
+  const uint32_t j0  = nbr[i];  // first list row, fetched together with the count (always a valid index, stale beyond cnt)
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  bool   crashed = false;
+  if (cnt) {
+    const PosRecord me = current_record(sw, rec, (uint32_t)i);
+    PosRecord       o  = current_record(sw, rec, j0);  // independent of `me`: one memory round trip for both
+    if (cell_of<true>(me.x, me.y, me.z).ok) {
+      for (uint32_t k = 0;;) {
+        if (cell_of<true>(o.x, o.y, o.z).ok && qualifies(me, o, crash)) apply_partner(me, o, crash, rebounce, fx, fy, fz, crashed);
+        if (++k >= cnt) break;
+        o = current_record(sw, rec, nbr[(size_t)k * sw.n + i]);
+      }
+    }
+  }
+  sw.S[(size_t)(F_FEXT + 0) * np + i] = fx;
+  sw.S[(size_t)(F_FEXT + 1) * np + i] = fy;
+  sw.S[(size_t)(F_FEXT + 2) * np + i] = fz;
+  if (crashed) sw.F[i] |= FLAG_CRASHED;
+}
+
+template <bool LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
-                                              double rebounce) {
+                                              double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id) {
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
   __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag
@@ -204,21 +284,38 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   __shared__ uint32_t  hit_j[64][HIT_CAP];
   __shared__ uint32_t  hit_n[64];
   __shared__ uint32_t  list_total, list_overflow, hit_overflow;  // two flags: each is only ever set, never downgraded
+  __shared__ uint32_t  nl_j[LISTS ? 64 : 1][LISTS ? LIST_CAP : 1];  // neighbour lists under construction
+  __shared__ uint32_t  nl_n[LISTS ? 64 : 1];
 
   const int       lane   = threadIdx.x;
   const int       i      = blockIdx.x * 64 + lane;
   const bool      active = i < sw.n;
+  if (LISTS) {
+    // the head table of the next rebuild must be empty: wipe it if the previous tick filled it (grid-strided, coalesced)
+    if (ctl[4 + (table_id ^ 1)]) {
+      const uint32_t stride = gridDim.x * 64u;
+      for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
+    }
+    if (!force && ctl[cur] == 0u) {  // wave-uniform: nobody has left its skin since the lists were built
+      if (active) list_tick(sw, rec, nbr, nbr_cnt, i, crash, rebounce);
+      return;
+    }
+    nl_n[lane] = 0;
+  }
   const long long gi     = my_offset + i;
   PosRecord       me;
   me.x = me.y = me.z = __longlong_as_double(0x7ff8000000000000ll);
   me.mass = me.arm_length = me.prop_radius = 0.0;
   if (active) me = rec[gi];
-  const Cell c = cell_of(me.x, me.y, me.z);
+  const Cell c = cell_of<LISTS>(me.x, me.y, me.z);
   me_s[lane]   = me;
   me_cell[lane] = make_int4(c.x, c.y, c.z, 0);
   hit_n[lane]  = 0;
   if (lane == 0) list_overflow = hit_overflow = 0;
 
+#ifdef MRS_QUERY_CLOCK
+  const unsigned long long t0 = clock_fence(0u);
+#endif
   // A: bucket heads.  Unconditional loads from always-valid addresses: a load under a divergent branch is waited for at
   // the join, which would serialise 27 memory round trips.
   uint2    info[27];
@@ -226,7 +323,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 #pragma unroll
   for (int q = 0; q < 27; q++) info[q] = head[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
   // this tick's table has been read: wipe the other one for the next tick (grid-strided, coalesced)
-  {
+  if (!LISTS) {
     const uint32_t stride = gridDim.x * 64u;
     for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
   }
@@ -244,6 +341,9 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 #if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 1
   if (tc == 0xFFFFFFFFu) sw.F[i] = tc;
   return;
+#endif
+#ifdef MRS_QUERY_CLOCK
+  const unsigned long long tA = clock_fence(tc);
 #endif
   // B: wave prefix sum -> slots in the pair list
   uint32_t inc = tc;
@@ -268,6 +368,9 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 #if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 2
   if (pair_e[lane].x == 0xFFFFFFFFu) sw.F[i] = 1;
   return;
+#endif
+#ifdef MRS_QUERY_CLOCK
+  const unsigned long long tB = clock_fence(pair_e[lane].x);
 #endif
   // C: uniform sweep over the list, U independent entries per lane and iteration so that their loads overlap
   constexpr int U = 4;
@@ -316,9 +419,16 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
       const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
       const int4      mc = me_cell[ow];
       const PosRecord o  = rec[pe[u].x - 1u];
-      const Cell      oc = cell_of(o.x, o.y, o.z);
+      const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
       if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
       const PosRecord m = me_s[ow];
+      if (LISTS) {
+        const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
+        if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
+          const uint32_t k = atomicAdd(&nl_n[ow], 1u);
+          if (k < (uint32_t)LIST_CAP) nl_j[ow][k] = pe[u].x - 1u;
+        }
+      }
       if (!qualifies(m, o, crash)) continue;
       const uint32_t k = atomicAdd(&hit_n[ow], 1u);
       if (k < HIT_CAP)
@@ -337,12 +447,15 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   if (hit_n[lane] == 0xFFFFFFFFu) sw.F[i] = 1;
   return;
 #endif
+#ifdef MRS_QUERY_CLOCK
+  const unsigned long long tC = clock_fence(hit_n[lane]);
+#endif
   // D: owners accumulate their hits in ascending partner index
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   if (active && c.ok) {
     if (list_overflow || (hit_overflow && hit_n[lane] > HIT_CAP)) {  // dense neighbourhood: the reference path
-      query_lane_sweeps(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
+      query_lane_sweeps<LISTS>(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
     } else {
       const uint32_t nh = hit_n[lane];
       uint32_t       prev = 0;
@@ -359,6 +472,31 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
       }
     }
   }
+  if (LISTS) {
+    // the lists of this wave: ascending, like the order partners are consumed in.  An incomplete list (more than LIST_CAP
+    // neighbours, or the dense fallback above, which does not collect them) keeps the next tick in rebuild mode.
+    uint32_t cnt = nl_n[lane];
+    if (list_overflow || cnt > (uint32_t)LIST_CAP) {
+      ctl[cur ^ 1] = 1u;
+      cnt = 0;
+    }
+    if (active) {
+      uint32_t prev = 0;
+      for (uint32_t r = 0; r < cnt; r++) {  // selection by repeated minimum, indices are distinct
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < cnt; k++) {
+          const uint32_t j = nl_j[lane][k];
+          if ((r == 0 || j > prev) && j < best) best = j;
+        }
+        nbr[(size_t)r * sw.n + i] = best;
+        prev = best;
+      }
+      nbr_cnt[i] = cnt;
+    }
+  }
+#ifdef MRS_QUERY_CLOCK  // timing build (tools/query_phases.py): the force columns carry phase durations in 10-ns ticks
+  fx = (double)(tA - t0); fy = (double)(tB - tA); fz = (double)(tC - tB);
+#endif
   if (active) {
     sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
     sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
@@ -374,11 +512,20 @@ struct CollideWork {
   uint32_t  cap_T = 0;
   int       cur   = 0;  // which head table the next tick fills; the other one is being wiped by that tick's query
   uint2 *   head[2] = {nullptr, nullptr}, *next = nullptr;
+  // neighbour lists (single-GPU ticks)
+  PosRecord* rec_build = nullptr;  // records of the last rebuild: reference positions of the skin test + airframe constants
+  uint32_t * nbr = nullptr, *nbr_cnt = nullptr, *ctl = nullptr;
+  int        fcur = 0;             // which of ctl[0..1] the next tick reads
+  bool       lists_live = false;   // rec_build / nbr describe this swarm as of some earlier tick
 };
 
 static void free_work(CollideWork* w) {
   (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
+  (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl);
   w->head[0] = w->head[1] = w->next = nullptr;
+  w->rec_build = nullptr;
+  w->nbr = w->nbr_cnt = w->ctl = nullptr;
+  w->lists_live = false;
 }
 
 extern "C" void mrs_collide_free(CollideWork* w) {
@@ -404,14 +551,17 @@ extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hip
     if (_e != hipSuccess) return _e; \
   } while (0)
 
-// rec_is_local_scratch: `rec` is this swarm's own (n_total == sw.n) record buffer that has NOT been packed yet — pack and hash
-// are then fused; otherwise `rec` holds ready (gathered) records
-extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
-                                      int crash, double rebounce, int rec_is_local_scratch, hipStream_t st) {
-  if (!*work) *work = new CollideWork();
-  CollideWork* w = *work;
-  uint32_t     T = 1024;
-  while ((long long)T < 4 * n_total) T <<= 1;  // load factor <= 0.25: ~27*0.25 false candidates per UAV
+// What the step kernel needs for the skin test (all null/zero while no neighbour lists are live).
+extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2) {
+  const bool on = w && w->lists_live;
+  *rec  = on ? w->rec_build : nullptr;
+  *flag = on ? w->ctl + w->fcur : nullptr;
+  *lim2 = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+}
+
+static hipError_t ensure_tables(CollideWork* w, long long n_total, hipStream_t st) {
+  uint32_t T = 1024;
+  while ((long long)T < MRS_TABLE_FACTOR * n_total) T <<= 1;  // load factor <= 0.25 (2x and 8x tables measured slower: more chains / more misses)
   if (n_total > w->cap_n || T > w->cap_T) {
     CK(hipStreamSynchronize(st));
     free_work(w);
@@ -424,19 +574,71 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
     w->cap_T = T;
     w->cur   = 0;
   }
-  T = w->cap_T;  // a larger table from an earlier call is still valid (both tables are empty between ticks)
-  const uint32_t mask = T - 1;
+  return hipSuccess;
+}
+
+// Plain search every tick over ready (gathered) records — the multi-GPU path, and single-GPU ticks with lists switched off
+// (rec_is_local_scratch: `rec` is this swarm's own, not yet packed, record buffer; pack and insert are then fused).
+extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
+                                      int crash, double rebounce, int rec_is_local_scratch, hipStream_t st) {
+  if (!*work) *work = new CollideWork();
+  CollideWork* w = *work;
+  CK(ensure_tables(w, n_total, st));
+  w->lists_live = false;  // the step kernel stops testing; a later list tick starts with a rebuild
+  const uint32_t T = w->cap_T, mask = T - 1;  // a larger table from an earlier call is still valid (both are empty between ticks)
   const unsigned gN   = (unsigned)((n_total + 255) / 256);
   uint2*         head = w->head[w->cur];
   uint2*         other = w->head[w->cur ^ 1];
   w->cur ^= 1;
   if (rec_is_local_scratch)
-    hipLaunchKernelGGL(k_pack_insert, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next);
+    hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0);
   else
-    hipLaunchKernelGGL(k_insert, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
-  // `other` was wiped by the previous query except for what that query's own tick left in it: nothing — it is the table of
-  // two ticks ago, wiped one tick ago.  This tick's table is wiped by the NEXT query; the very first tick starts from memset.
-  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
-                     rebounce);
+    hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
+  hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
+                     rebounce, nullptr, 0, 1, nullptr, nullptr, 0);
+  return hipGetLastError();
+}
+
+// Single-GPU tick with neighbour lists.  force_rebuild: the host changed positions or airframe constants since the last call.
+// number of list rebuilds so far (device counter; synchronises the stream)
+extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out) {
+  *out = 0;
+  if (!w || !w->ctl) return hipSuccess;
+  CK(hipMemcpyAsync(out, w->ctl + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
+extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st) {
+  if (!*work) *work = new CollideWork();
+  CollideWork*    w = *work;
+  const long long n = sw.n;
+  CK(ensure_tables(w, n, st));
+  if (!w->rec_build) {
+    CK(hipMalloc(&w->rec_build, sizeof(PosRecord) * (size_t)w->cap_n));
+    CK(hipMalloc(&w->nbr, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n));
+    CK(hipMalloc(&w->nbr_cnt, sizeof(uint32_t) * (size_t)w->cap_n));
+    CK(hipMemsetAsync(w->nbr, 0, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n, st));  // rows beyond a UAV's count are read (not used)
+    CK(hipMalloc(&w->ctl, sizeof(uint32_t) * 8));  // [0..1] skin flags, [2] rebuild counter, [4..5] "head table t holds entries"
+    CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
+    w->fcur = 0;
+  }
+  if (!w->lists_live) {  // first list tick, or plain-search ticks came in between: start from empty tables and flags
+    CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * (size_t)w->cap_T, st));
+    CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * (size_t)w->cap_T, st));
+    CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
+    w->fcur = 0;
+  }
+  const int force = (force_rebuild || !w->lists_live) ? 1 : 0;
+  const uint32_t T = w->cap_T, mask = T - 1;
+  const int      tid  = w->cur;
+  uint2*         head = w->head[tid];
+  uint2*         other = w->head[tid ^ 1];
+  w->cur ^= 1;
+  hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
+                     w->fcur, force, tid);
+  hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
+                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
+  w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
+  w->lists_live = true;
   return hipGetLastError();
 }

@@ -29,6 +29,9 @@ extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hip
 struct CollideWork;
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                       int crash, double rebounce, int rec_is_local_scratch, hipStream_t st);
+extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st);
+extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
+extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" void mrs_collide_free(CollideWork* w);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
@@ -239,6 +242,9 @@ struct mrs_swarm {
   // collision scratch
   PosRecord*   dRec = nullptr;
   CollideWork* cwork = nullptr;
+  bool         use_lists = true;   // single-GPU collision ticks reuse neighbour lists between rebuilds (tuning: MRS_NEIGHBOUR_LISTS=0)
+  bool         nbr_dirty = true;   // the host wrote positions or airframe constants since the last collision tick
+  int64_t      collision_ticks = 0;
   // profiling
   int  profiling = 0;  // 0 off, 1 one event pair around the whole step_n/tick_n region, 2 one pair per step launch
   std::vector<hipEvent_t> ev;
@@ -258,7 +264,11 @@ struct mrs_swarm {
 
   bool      fext_active = false;  // apply_force / collisions were used at least once
 
-  SwarmDev view() const { return SwarmDev{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size(), fext_active ? 1u : 0u}; }
+  SwarmDev view() const {
+    SwarmDev v{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size(), fext_active ? 1u : 0u, nullptr, nullptr, 0.0};
+    mrs_collide_step_hook(cwork, &v.vl_rec, &v.vl_flag, &v.vl_lim2);
+    return v;
+  }
 };
 
 static void track_mode(mrs_swarm* s, int first, int count, int mode) {
@@ -314,6 +324,7 @@ static TypeKey make_key(const mrs_model_params_t* p) {
 
 static int upload_blocks(mrs_swarm* s) {
   if (!s->blocks_dirty) return MRS_OK;
+  s->nbr_dirty = true;  // some UAV changed its airframe type
   const int nb = s->npad / 64;
   s->block_type.assign((size_t)nb, 0);
   s->mixed_blocks.clear();
@@ -344,6 +355,7 @@ static int upload_types(mrs_swarm* s, double dt) {
     int rcb = upload_blocks(s);
     if (rcb) return rcb;
   }
+  if (s->types_dirty) s->nbr_dirty = true;  // mass / arm length / propeller radius of the collision records may have changed
   if (!s->types_dirty && dt == s->table_dt) return MRS_OK;
   if (dt != s->table_dt) {
     for (size_t i = 0; i < s->keys.size(); i++) {
@@ -370,6 +382,7 @@ static int upload_types(mrs_swarm* s, double dt) {
 
 // upload one column (count doubles from the staging vector) into field f at [first, first+count)
 static int put_column(mrs_swarm* s, int f, int first, int count, const double* col) {
+  if (f >= F_X && f < F_X + 3) s->nbr_dirty = true;
   HIPCHK(hipMemcpyAsync(s->dS + (size_t)f * s->npad + first, col, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return MRS_OK;
@@ -535,6 +548,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   mrs_swarm* s = new mrs_swarm();
   s->n         = n_uavs;
   s->npad      = ((n_uavs + 63) / 64) * 64;
+  if (const char* e = getenv("MRS_NEIGHBOUR_LISTS")) s->use_lists = atoi(e) != 0;
   if (s->npad == 0) s->npad = 64;
   s->device = device_id;
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -903,8 +917,14 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
   if (rc) return rc;
-  if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
   s->fext_active = true;
+  s->collision_ticks++;
+  if (s->use_lists) {
+    HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, crash, rebounce, s->nbr_dirty ? 1 : 0, s->stream));
+    s->nbr_dirty = false;
+    return MRS_OK;
+  }
+  if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
   HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->dRec, s->n, 0, crash, rebounce, /*rec_is_local_scratch=*/1, s->stream));
   return MRS_OK;
 }
@@ -1084,6 +1104,17 @@ int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_
   HIPCHK(hipMemcpyAsync(s->hOut, s->dOut, sizeof(mrs_uav_output_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   memcpy(out, s->hOut, sizeof(mrs_uav_output_t) * (size_t)count);
+  return MRS_OK;
+}
+
+int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds) {
+  MRS_LOCK(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  HIPCHK(hipSetDevice(s->device));
+  unsigned rb = 0;
+  HIPCHK(mrs_collide_rebuilds(s->cwork, s->stream, &rb));
+  if (n_ticks) *n_ticks = s->collision_ticks;
+  if (n_rebuilds) *n_rebuilds = s->use_lists ? (int64_t)rb : s->collision_ticks;
   return MRS_OK;
 }
 

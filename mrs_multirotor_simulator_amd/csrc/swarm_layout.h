@@ -63,6 +63,7 @@ struct TypeParams {
 };
 
 // ---- device view of a swarm ----
+struct PosRecord;
 struct SwarmDev {
   double*             S;      // F_COUNT x npad
   uint32_t*           F;      // npad
@@ -72,6 +73,10 @@ struct SwarmDev {
   const int32_t*      MB;     // indices of the mixed blocks (n_mixed entries)
   int32_t             n, npad, n_mixed;
   uint32_t            opts;   // bit 0: some UAV may carry a non-zero external force (else the F_FEXT columns are not read)
+  // skin test of the collision pass's neighbour lists (collide.hip); vl_flag == nullptr: no lists are live
+  const PosRecord*    vl_rec;   // per-UAV record holding the position at the last list rebuild
+  uint32_t*           vl_flag;  // set to 1 when some UAV is farther than sqrt(vl_lim2) from that position
+  double              vl_lim2;
 };
 
 // 48-byte record exchanged for the collision pass (single- and multi-GPU): everything

@@ -555,3 +555,62 @@ def test_full_size_100k_collision_tick_against_oracle(M, oracle):
     assert np.abs(fg.sum(axis=0)).max() < 1e-9 * np.abs(fg).sum()
     p.both("handle_collisions", False, True, 100.0)
     assert np.array_equal(p.g.has_crashed(), p.o.has_crashed()) and p.o.has_crashed().sum() == touched
+
+
+def test_neighbour_lists_are_reused_and_rebuilt_with_identical_results(M, oracle):
+    """Collision ticks between two neighbour searches work from the stored lists (collide.hip).  300 ticks of a swarm whose UAVs
+    fly up to ~20 m/s, so the lists go stale every few dozen ticks: forces, crash-free state and PIDs must follow the oracle
+    (which searches on every tick) the whole way, and the statistics must show that most ticks did NOT search."""
+    rng = np.random.default_rng(77)
+    n = 4000
+    side = (64.0 * n) ** (1.0 / 3.0)
+    p = Pair(M, n)
+    pos = rng.uniform(0, side, (n, 3)) + [0, 0, 50]
+    pos[:300] = pos[300:600] + rng.normal(0, 0.35, (300, 3))  # touching pairs from the first tick on
+    p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n))
+    st = helpers.random_state(rng, n, 4, tilted=True)
+    st["x"] = pos
+    st["v"] = rng.normal(0, 6.0, (n, 3))
+    p.set_state(0, n, st)
+    p.both("set_input", 0, n, oracle.ACTUATOR_CMD, rng.uniform(0.4, 0.55, (n, 4)))
+    touched = 0
+    for chunk in range(6):
+        for _ in range(50):
+            p.o.step(DT)
+            p.o.handle_collisions(True, False, 100.0)
+        p.g.tick_n(DT, 50, True, False, 100.0)
+        fo = p.o.get_external_force()
+        helpers.assert_close(p.g.get_external_force(), fo, 1e-12, f"forces after {50 * (chunk + 1)} ticks")
+        p.compare(RTOL_LITERAL, f"state after {50 * (chunk + 1)} ticks")
+        touched = max(touched, int((np.abs(fo).sum(axis=1) > 0).sum()))
+    assert touched > 100
+    ticks, rebuilds = p.g.collision_stats()
+    assert ticks == 300
+    assert 3 <= rebuilds <= 100, f"{rebuilds} neighbour searches in {ticks} ticks"
+
+
+def test_neighbour_lists_follow_host_writes(M, oracle):
+    """set_state / set_mass between collision ticks invalidate the stored lists (positions at the last search, airframe constants)."""
+    rng = np.random.default_rng(78)
+    n = 600
+    p = Pair(M, n)
+    pos = rng.uniform(0, 60, (n, 3)) + [0, 0, 20]
+    p.construct(0, n, "x500", pos=pos, heading=np.zeros(n))
+    p.both("handle_collisions", True, False, 100.0)
+    p.both("handle_collisions", True, False, 100.0)  # list tick
+    helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "before the writes")
+    # teleport UAV 5 next to UAV 400 (they were nowhere near each other when the lists were built)
+    st = {k: v[5:6].copy() for k, v in p.o.get_state().items()}
+    st["x"][0] = p.o.get_state()["x"][400] + [0.3, 0.1, -0.2]
+    p.both("set_state", 5, 1, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    p.both("handle_collisions", True, False, 100.0)
+    fo = p.o.get_external_force()
+    assert np.abs(fo[5]).sum() > 0 and np.abs(fo[400]).sum() > 0
+    helpers.assert_close(p.g.get_external_force(), fo, 1e-12, "after set_state")
+    # the force depends on both masses (src/multirotor_simulator.cpp:350)
+    p.both("set_mass", 400, 1, 5.0)
+    p.both("handle_collisions", True, False, 100.0)
+    helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "after set_mass")
+    # crash mode from the lists
+    p.both("handle_collisions", False, True, 100.0)
+    assert np.array_equal(p.g.has_crashed(), p.o.has_crashed()) and p.o.has_crashed()[[5, 400]].all()
