@@ -185,8 +185,8 @@ def main():
     assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
     if rank == 0:
         key = "actuator" if args.workload == "actuator" else "position"
-        per_launch_steps = args.substeps if not coll else 1
-        alg_bytes = BYTES_PER_UAV_STEP[key] * n * per_launch_steps
+        # one launch reads and writes the state once, however many sub-steps it fuses: no roofline credit for fusion
+        alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args, n)
         out = {
