@@ -233,10 +233,19 @@ public:
     mrs_throw_on_error(mrs_swarm_tick_n(s_, dt, n_ticks, enabled, crash, rebounce));
   }
   void synchronize() { mrs_throw_on_error(mrs_swarm_synchronize(s_)); }
+  // collision ticks so far, and how many of them had to repeat the neighbour search
+  std::pair<int64_t, int64_t> collisionStats() {
+    int64_t t = 0, r = 0;
+    mrs_throw_on_error(mrs_swarm_get_collision_stats(s_, &t, &r));
+    return {t, r};
+  }
 
   // ---- UavSystemRos semantics that live on the device ----
   // timeoutInput() for UAVs [first, first+count): safe command of the same mode (src/uav_system_ros.cpp:474-647)
   void timeoutInput(int first, int count) { mrs_throw_on_error(mrs_swarm_timeout_input(s_, first, count)); }
+  // UavSystemRos::makeStep iterates the model only `if (_iterate_without_input_ || time_last_input_ > 0)` (:265): UAVs on hold
+  // are skipped by makeStep / tick
+  void setHold(int first, int count, bool hold) { mrs_throw_on_error(mrs_swarm_set_hold(s_, first, count, hold ? 1 : 0)); }
   // callbackSetMass / callbackSetGroundZ (src/uav_system_ros.cpp:1028-1080)
   void setMass(int first, int count, double mass) { mrs_throw_on_error(mrs_swarm_set_mass(s_, first, count, mass)); }
   void setGroundZ(int first, int count, double ground_z) { mrs_throw_on_error(mrs_swarm_set_ground_z(s_, first, count, ground_z)); }

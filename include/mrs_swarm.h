@@ -140,6 +140,9 @@ int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int3
 int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const double* force);
 /* UavSystem::crash / hasCrashed — uav_system.hpp:278,286 */
 int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count);
+/* UavSystemRos::makeStep iterates the model only `if (_iterate_without_input_ || time_last_input_ > 0)` — src/uav_system_ros.cpp:265.
+ * hold != 0 excludes the UAVs from mrs_swarm_step* / tick (state, PIDs and IMU stay as they are); collisions still see them. */
+int mrs_swarm_set_hold(mrs_swarm_t* s, int32_t first, int32_t count, int32_t hold);
 int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out);
 
 /* ---- UavSystemRos semantics that touch device state ---- */

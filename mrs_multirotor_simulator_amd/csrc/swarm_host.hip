@@ -776,6 +776,15 @@ int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
   return flags_update(s, first, count, ~0u, FLAG_CRASHED);
 }
 
+int mrs_swarm_set_hold(mrs_swarm_t* s, int32_t first, int32_t count, int32_t hold) {
+  MRS_LOCK(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  return flags_update(s, first, count, ~FLAG_HOLD, hold ? FLAG_HOLD : 0u);
+}
+
 int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out) {
   MRS_LOCK(s);
   int rc = check_range(s, first, count);

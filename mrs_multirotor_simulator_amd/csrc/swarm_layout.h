@@ -36,6 +36,8 @@ enum {
 #define FLAG_VPREV_SPLIT 0x400u   // v_prev differs from v: the F_VPREV column is authoritative.  After every step v_prev == v
                                   // (multirotor_model.hpp:281), so the step kernel neither reads nor writes F_VPREV unless
                                   // MultirotorModel::setState changed v in between (:424-433 leaves v_prev alone)
+#define FLAG_HOLD       0x800u     // UavSystemRos: the model is not iterated (no input yet / input timed out, and
+                                  // iterate_without_input == false)            src/uav_system_ros.cpp:265
 #define FLAG_TYPE_SHIFT 16         // 16 bits: index into the type table
 #define MRS_MAX_TYPES  65536
 

@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
-    "mrs_swarm_get_collision_stats", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
+    "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
 _lib = None
@@ -154,6 +154,7 @@ def load_library():
         "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
+        "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_collision_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
@@ -293,6 +294,10 @@ class Swarm:
         st = C.c_void_p()
         _check(_lib.mrs_swarm_stream(self._h, C.byref(st)))
         return st.value
+
+    def set_hold(self, first, count, hold):
+        """UAVs on hold are not iterated by step/tick (UavSystemRos without input and iterate_without_input == false)."""
+        _check(_lib.mrs_swarm_set_hold(self._h, int(first), int(count), int(bool(hold))))
 
     def collision_stats(self):
         """(collision ticks, ticks that repeated the neighbour search)"""

@@ -96,6 +96,7 @@ def lib():
         L.orc_swarm_handle_collisions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
         L.orc_swarm_apply_force.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
         L.orc_swarm_crash.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.orc_swarm_set_hold.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.orc_swarm_has_crashed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ip]
         L.orc_swarm_get_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [dp] * 6
         L.orc_swarm_set_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [dp] * 5
@@ -207,6 +208,9 @@ class OracleSwarm:
 
     def crash(self, first, count):
         lib().orc_swarm_crash(self._h, first, count)
+
+    def set_hold(self, first, count, hold):
+        lib().orc_swarm_set_hold(self._h, first, count, int(bool(hold)))
 
     def has_crashed(self, first=0, count=None):
         count = self.n - first if count is None else count

@@ -222,6 +222,7 @@ typedef struct {
   double y[18]; /* internal_state_ */
   /* UavSystem (uav_system.hpp:77-117) */
   int crashed, active_input;
+  int hold; /* UavSystemRos: no input yet / input timed out and iterate_without_input == false (src/uav_system_ros.cpp:265) */
   double actuators[ORC_MAX_MOTORS];
   double control_group[4];            /* roll pitch yaw throttle */
   double attitude_rate[4];            /* rx ry rz throttle */
@@ -1051,7 +1052,8 @@ void orc_swarm_set_feedforward(orc_swarm_t* s, int32_t first, int32_t count, int
 }
 
 void orc_swarm_step(orc_swarm_t* s, double dt) {
-  for (int i = 0; i < s->n; i++) uav_make_step(&s->u[i], dt, &s->diag);
+  for (int i = 0; i < s->n; i++)
+    if (!s->u[i].hold) uav_make_step(&s->u[i], dt, &s->diag); /* src/uav_system_ros.cpp:265-271 */
 }
 
 typedef struct {
@@ -1064,7 +1066,8 @@ typedef struct {
 static void* step_worker(void* arg) {
   step_job_t* j = (step_job_t*)arg;
   for (int k = 0; k < j->n_steps; k++)
-    for (int i = j->lo; i < j->hi; i++) uav_make_step(&j->s->u[i], j->dt, &j->diag);
+    for (int i = j->lo; i < j->hi; i++)
+      if (!j->s->u[i].hold) uav_make_step(&j->s->u[i], j->dt, &j->diag);
   return NULL;
 }
 
@@ -1199,6 +1202,9 @@ void orc_swarm_handle_collisions(orc_swarm_t* s, int32_t enabled, int32_t crash,
 
 void orc_swarm_apply_force(orc_swarm_t* s, int32_t first, int32_t count, const double* force) {
   for (int k = 0; k < count; k++) memcpy(s->u[first + k].ext_force, &force[3 * k], 3 * sizeof(double));
+}
+void orc_swarm_set_hold(orc_swarm_t* s, int32_t first, int32_t count, int32_t hold) {
+  for (int k = 0; k < count; k++) s->u[first + k].hold = hold != 0;
 }
 void orc_swarm_crash(orc_swarm_t* s, int32_t first, int32_t count) {
   for (int k = 0; k < count; k++) s->u[first + k].crashed = 1;

@@ -134,6 +134,7 @@ void orc_swarm_step_n(orc_swarm_t* s, double dt, int32_t n_steps, int32_t n_thre
 void orc_swarm_handle_collisions(orc_swarm_t* s, int32_t enabled, int32_t crash, double rebounce);
 
 void orc_swarm_apply_force(orc_swarm_t* s, int32_t first, int32_t count, const double* force);  /* uav_system.hpp:295 */
+void orc_swarm_set_hold(orc_swarm_t* s, int32_t first, int32_t count, int32_t hold);              /* src/uav_system_ros.cpp:265 */
 void orc_swarm_crash(orc_swarm_t* s, int32_t first, int32_t count);                              /* :278 */
 void orc_swarm_has_crashed(const orc_swarm_t* s, int32_t first, int32_t count, int32_t* out);     /* :286 */
 

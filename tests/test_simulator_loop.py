@@ -1,0 +1,78 @@
+"""SURVEY 8f ranks 1 and 3 — the simulator loop around the hot path (include/mrs_multirotor_simulator/multirotor_simulator.hpp):
+sim clock, tick order, input watchdog / hold mask, RTF telemetry, pacing, pause, randd.  The loop logic is unit-tested on the CPU
+with a recording stand-in for the swarm; the hold mask itself is checked on the GPU against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import RTOL_LITERAL, Pair
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT = 0.001
+
+
+def test_simulator_loop_logic_cpp():
+    exe = os.path.join(ROOT, "tests", "cpp", "simulator_logic_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DMRS_NO_EIGEN", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "simulator_logic_test.cpp"), "-o", exe, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for tag in ("clock", "clock_same_rate", "watchdog", "watchdog_iterate", "rtf", "pacing", "randd"):
+        assert f"ok {tag}" in out.stdout
+
+
+def test_oracle_hold_mask_skips_the_model():
+    """src/uav_system_ros.cpp:265: a UAV without input is not iterated when iterate_without_input is false."""
+    from oracle import oracle_swarm as O
+    o = O.OracleSwarm(3)
+    o.construct(0, 3, helpers.oracle_params("x500"), np.array([[0, 0, 5.0]] * 3), np.zeros(3))
+    o.set_input(0, 3, O.ACTUATOR_CMD, np.full((3, 4), 0.3))
+    o.set_hold(1, 1, True)
+    before = o.get_state()
+    o.step_n(DT, 20)
+    after = o.get_state()
+    assert np.array_equal(after["x"][1], before["x"][1]) and np.array_equal(after["motor_rpm"][1], before["motor_rpm"][1])
+    assert after["x"][0][2] < before["x"][0][2] and np.array_equal(after["x"][0], after["x"][2])
+    o.set_hold(1, 1, False)
+    o.step_n(DT, 20)
+    assert o.get_state()["x"][1][2] < before["x"][1][2]
+
+
+@pytest.mark.gpu
+def test_hold_mask_matches_oracle(mrs, oracle):
+    """UAVs on hold keep state, PIDs and IMU through steps and ticks; collisions still see them; release resumes."""
+    rng = np.random.default_rng(31)
+    n = 300
+    p = Pair(mrs, n)
+    pos = rng.uniform(0, 14, (n, 3)) + [0, 0, 10]
+    p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n))
+    goals = np.concatenate([pos + rng.uniform(-3, 3, (n, 3)), rng.uniform(-3, 3, (n, 1))], axis=1)
+    p.both("set_input", 0, n, oracle.POSITION_CMD, goals)
+    p.step(DT, 30)
+    held = np.zeros(n, bool)
+    held[40:170] = True   # covers whole 64-UAV blocks and partial ones
+    held[200] = True
+    for lo, hi in ((40, 170), (200, 201)):
+        p.both("set_hold", lo, hi - lo, True)
+    frozen = p.g.get_state()
+    for _ in range(40):
+        p.o.step(DT)
+        p.o.handle_collisions(True, False, 100.0)
+    p.g.tick_n(DT, 40, True, False, 100.0)
+    p.compare(RTOL_LITERAL, "with hold")
+    now = p.g.get_state()
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        assert np.array_equal(now[k][held], frozen[k][held]), k
+    assert not np.array_equal(now["x"][~held], frozen["x"][~held])
+    helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), 1e-12, "forces on and from held UAVs")
+    assert np.abs(p.o.get_external_force()[held]).sum() > 0
+    # the watchdog's other half: safe command, then release
+    p.both("timeout_input", 40, 130)
+    p.both("set_hold", 40, 130, False)
+    p.both("set_hold", 200, 1, False)
+    p.step(DT, 40)
+    p.compare(RTOL_LITERAL, "after release")
+    assert not np.array_equal(p.g.get_state()["x"][held], frozen["x"][held])
