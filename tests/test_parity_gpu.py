@@ -614,3 +614,43 @@ def test_neighbour_lists_follow_host_writes(M, oracle):
     # crash mode from the lists
     p.both("handle_collisions", False, True, 100.0)
     assert np.array_equal(p.g.has_crashed(), p.o.has_crashed()) and p.o.has_crashed()[[5, 400]].all()
+
+
+def test_full_size_1M_uavs_replica_property_and_oracle_sample(M, oracle):
+    """BASELINE config 5's size on one GPU: 1 000 000 UAVs, built as 244 copies of a 4096-UAV swarm (+ remainder), position
+    cascade with ground contact.  Size-independent properties: every copy must end bit-identical to the first one (no
+    cross-talk between lanes, blocks or the tail block), and the first copy must follow the oracle."""
+    rng = np.random.default_rng(55)
+    m, n = 4096, 1_000_000
+    reps = -(-n // m)
+    st = random_state(rng, m, 4, box=50.0, zlo=0.2, zhi=30.0, tilted=True)
+    st["x"][:300, 2] = rng.uniform(0.0, 0.05, 300)  # these come down on the ground plane within the first steps
+    st["v"][:300, 2] = -3.0
+    cmd = np.concatenate([st["x"] + rng.uniform(-4, 4, (m, 3)), rng.uniform(-3, 3, (m, 1))], axis=1)
+    cmd[:, 2] = np.abs(cmd[:, 2])
+    tile = lambda a: np.concatenate([a] * reps, axis=0)[:n]
+    g = M.Swarm(n, arith=M.ARITH_FAST)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), tile(st["x"]), np.zeros(n))
+    for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+        getattr(g, nm)(0, n)
+    g.set_state(0, n, tile(st["x"]), tile(st["v"]), tile(st["R"]), tile(st["omega"]), tile(st["motor_rpm"]))
+    g.set_input(0, n, oracle.POSITION_CMD, tile(cmd))
+    g.step_n(DT, 200)
+    out = g.get_state()
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        a = out[k]
+        first = a[:m]
+        for r in range(1, reps):
+            blk = a[r * m:(r + 1) * m]
+            assert np.array_equal(blk, first[:len(blk)]), f"{k}: copy {r} differs from copy 0"
+    o = oracle.OracleSwarm(m)
+    o.construct(0, m, helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(m))
+    for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+        getattr(o, nm)(0, m)
+    o.set_state(0, m, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, m, oracle.POSITION_CMD, cmd)
+    o.step_n(DT, 200)
+    ref = o.get_state()
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"1M swarm, first copy vs oracle: {k}")
+    assert (ref["x"][:, 2] <= 1e-9).any(), "some UAVs should be sitting on the ground plane"
