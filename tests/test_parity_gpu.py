@@ -654,3 +654,77 @@ def test_full_size_1M_uavs_replica_property_and_oracle_sample(M, oracle):
     for k in ("x", "v", "R", "omega", "motor_rpm"):
         helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"1M swarm, first copy vs oracle: {k}")
     assert (ref["x"][:, 2] <= 1e-9).any(), "some UAVs should be sitting on the ground plane"
+
+
+def test_pointer_addressed_kernels_match_buffer_addressed_ones(M):
+    """Swarms below 4 GiB of state use buffer-addressed columns (step_device.inc, SwarmAcc<true>); larger ones the 64-bit pointer
+    form.  The choice is made once per process, so both forms run in child processes: LITERAL results must agree bit for bit,
+    FAST ones to the last few bits."""
+    import subprocess, sys, os, json
+    code = r'''
+import json, numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mrs_multirotor_simulator_amd as M
+import helpers
+rng = np.random.default_rng(12)
+n = 700
+out = {}
+for arith in (M.ARITH_LITERAL, M.ARITH_FAST):
+    g = M.Swarm(n, arith=arith)
+    st = helpers.random_state(rng, n, 4, box=20.0, zlo=0.1, zhi=8.0, tilted=True)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(n))
+    g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    g.set_input(0, n, M.POSITION_CMD, np.concatenate([st["x"] + 1.0, np.zeros((n, 1))], axis=1))
+    g.set_input(0, 100, M.ACTUATOR_CMD, rng.uniform(0.3, 0.6, (100, 4)))
+    g.step_n(0.001, 60)
+    g.step_n(0.001, 4, 5)
+    s = g.get_state()
+    out[str(arith)] = {k: s[k].tolist() for k in ("x", "R", "motor_rpm")}
+    out[str(arith)]["pid"] = g.get_pid().tolist()
+print("RESULT" + json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for env_extra in ({}, {"MRS_NO_BUFFER_ADDRESSING": "1"}):
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0][6:]))
+    for arith in res[0]:
+        for k in res[0][arith]:
+            a, b = np.array(res[0][arith][k]), np.array(res[1][arith][k])
+            if int(arith) == M.ARITH_LITERAL:
+                assert np.array_equal(a, b), f"literal: {k}"
+            else:  # FMA contraction is the compiler's choice per instantiation: last-bit differences are allowed here
+                helpers.assert_close(a, b, RTOL_FAST, f"fast: {k}")
+
+
+def test_state_array_beyond_2_GiB_still_addresses_every_column(M, oracle):
+    """3.2 M UAVs = 2.2 GiB of state: the 32-bit buffer offsets of the step kernel run past 2^31.  Replica property (all copies
+    of a 4096-UAV swarm stay bit-identical, the last column of the last copy included) + the first copy against the oracle."""
+    rng = np.random.default_rng(56)
+    m, n = 4096, 3_200_000
+    reps = -(-n // m)
+    st = random_state(rng, m, 4)
+    cmd = rng.uniform(0.35, 0.6, (m, 4))
+    tile = lambda a: np.concatenate([a] * reps, axis=0)[:n]
+    g = M.Swarm(n, arith=M.ARITH_FAST)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), tile(st["x"]), np.zeros(n))
+    g.set_state(0, n, tile(st["x"]), tile(st["v"]), tile(st["R"]), tile(st["omega"]), tile(st["motor_rpm"]))
+    g.set_input(0, n, oracle.ACTUATOR_CMD, tile(cmd))
+    g.step_n(DT, 50)
+    out = g.get_state()
+    imu = g.get_imu()
+    del g
+    for k, a in list(out.items()) + [("imu", imu)]:
+        first = a[:m]
+        for r in range(1, reps):
+            blk = a[r * m:(r + 1) * m]
+            assert np.array_equal(blk, first[:len(blk)]), f"{k}: copy {r} differs from copy 0"
+    o = oracle.OracleSwarm(m)
+    o.construct(0, m, helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(m))
+    o.set_state(0, m, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, m, oracle.ACTUATOR_CMD, cmd)
+    o.step_n(DT, 50)
+    ref = o.get_state()
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"3.2M swarm, first copy vs oracle: {k}")
