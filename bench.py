@@ -189,6 +189,12 @@ def main():
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args, n)
+        # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD
+        npad = (n + 63) // 64 * 64
+        kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
+        if 86 * npad * 8 < 2 ** 32:
+            kernel_name += "_buf" + ("_w3" if (args.substeps == 1 and npad // 64 > 2048) else "")
+        kernel_name += "_" + args.arith
         out = {
             "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -199,8 +205,8 @@ def main():
                        "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and world > 1)
                                        else f"{world} independent shard(s), no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": (("mrs_uav_model_step_" if args.workload == "actuator" else "mrs_uav_step_") + args.arith) if not coll
-                         else "whole tick: mrs_uav_step_" + args.arith + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name if not coll
+                         else "whole tick: " + kernel_name + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
                          "method": "one hipEvent pair around the timed region on the swarm's stream: elapsed / launches (inter-launch gaps included)"},
         }
