@@ -76,3 +76,26 @@ def test_hold_mask_matches_oracle(mrs, oracle):
     p.step(DT, 40)
     p.compare(RTOL_LITERAL, "after release")
     assert not np.array_equal(p.g.get_state()["x"][held], frozen["x"][held])
+
+
+def _build_cpp(mrs, name):
+    from mrs_multirotor_simulator_amd import swarm
+    exe = os.path.join(ROOT, "tests", "cpp", name)
+    libdir = os.path.dirname(swarm.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DMRS_NO_EIGEN", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe, "-L", libdir, "-lmrs_swarm", "-lpthread",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_simulator_over_the_swarm_compiles(mrs):
+    assert os.path.exists(_build_cpp(mrs, "simulator_gpu_test"))
+
+
+@pytest.mark.gpu
+def test_simulator_over_the_swarm_on_gpu(mrs):
+    """MultirotorSimulator<UavSwarm>: frozen without input, only commanded UAVs move, timeout -> hover command + hold, pacing."""
+    out = subprocess.run([_build_cpp(mrs, "simulator_gpu_test")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for tag in ("frozen_without_input", "only_commanded_uavs_move", "timeout_puts_on_hold", "paced"):
+        assert f"ok {tag}" in out.stdout, out.stdout
