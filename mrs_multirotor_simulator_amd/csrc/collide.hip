@@ -18,7 +18,7 @@
 //            keeps the previous head as its `next` link.  No counting pass, no prefix sum, no scatter.
 //   query  : one single-wave workgroup per 64 local UAVs fetches the 27 bucket heads per lane, follows the (rare) chains and
 //            evaluates the literal predicate; partners are consumed in ascending index, which makes the result
-//            independent of the atomic arrival order.  It also clears the OTHER head table for the next tick.
+//            independent of the atomic arrival order.  The head table a later search will fill is wiped by the tick before it.
 //
 // Neighbour lists (single-GPU ticks): UAVs move centimetres per tick, so the partner search above is only REPEATED when it
 // has to be.  A rebuild tick runs insert + query with 2.25-m cells and keeps, per UAV, the ascending list of every UAV
@@ -26,7 +26,8 @@
 // with the recorded one (step_device.inc) and raises a flag once any UAV has moved more than SKIN/2; until then a pair
 // closer than sqrt(3) now was closer than sqrt(3) + SKIN at the rebuild, i.e. is in the lists, and a tick is ONE cheap
 // pass: current positions of the listed UAVs -> literal predicate -> forces / crash flags, in the same ascending order.
-// The decision is taken on the device (both kernels are always launched; insert returns at once on a list tick), host
+// The decision is taken on the device (both kernels are always launched: on a list tick the insert kernel evaluates the lists
+// and the query kernel returns at once), host
 // writes to positions or airframe constants force a rebuild, and a UAV with more than LIST_CAP listed neighbours keeps
 // the pass in rebuild mode.  Results are identical to searching every tick.
 #include <hip/hip_runtime.h>
@@ -120,34 +121,6 @@ __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask,
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_total) return;
   insert_uav(j, cell_of<LISTS>(rec[j].x, rec[j].y, rec[j].z), mask, head, next);
-}
-
-// single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them).
-// With LISTS the pass only happens on a rebuild tick; the records then double as the reference positions of the skin test.
-template <bool LISTS>
-__global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
-                              int table_id) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (LISTS) {
-    const bool rebuild = force || ctl[cur] != 0u;
-    if (i == 0) {
-      ctl[cur ^ 1]     = 0u;  // the next tick's flag: the step kernel (or this tick's query, on list overflow) raises it
-      ctl[4 + table_id] = rebuild ? 1u : 0u;  // "this head table holds entries": the next tick's query wipes it if so
-      if (rebuild) ctl[2] += 1u;              // statistics: number of rebuild ticks
-    }
-    if (!rebuild) return;
-  }
-  if (i >= sw.n) return;
-  const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
-  PosRecord r;
-  r.x = sw.S[(size_t)(F_X + 0) * sw.npad + i];
-  r.y = sw.S[(size_t)(F_X + 1) * sw.npad + i];
-  r.z = sw.S[(size_t)(F_X + 2) * sw.npad + i];
-  r.mass        = P.mass;
-  r.arm_length  = P.arm_length;
-  r.prop_radius = P.prop_radius;
-  rec[i] = r;
-  insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
 // ---- query ----
@@ -273,6 +246,44 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
   if (crashed) sw.F[i] |= FLAG_CRASHED;
 }
 
+// single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them).
+// With LISTS the pass only happens on a rebuild tick (the records then double as the reference positions of the skin test);
+// on every other tick this light kernel evaluates the neighbour lists and the query kernel that follows returns at once.
+template <bool LISTS>
+__global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
+                              int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
+                              double rebounce) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (LISTS) {
+    const bool rebuild = force || ctl[cur] != 0u;
+    if (i == 0) {
+      ctl[cur ^ 1]     = 0u;  // the next tick's flag: the step kernel (or this tick's query, on list overflow) raises it
+      ctl[4 + table_id] = rebuild ? 1u : 0u;  // "this head table holds entries": the next tick wipes it if so
+      if (rebuild) ctl[2] += 1u;              // statistics: number of rebuild ticks
+    }
+    // the head table of the NEXT rebuild must be empty: wipe it if the previous tick filled it (grid-strided, coalesced)
+    if (ctl[4 + (table_id ^ 1)]) {
+      const uint32_t stride = gridDim.x * blockDim.x;
+      for (uint32_t t = (uint32_t)i; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
+    }
+    if (!rebuild) {  // wave-uniform: nobody has left its skin since the lists were built — this kernel IS the collision tick
+      if (i < sw.n) list_tick(sw, rec, nbr, nbr_cnt, i, crash, rebounce);
+      return;
+    }
+  }
+  if (i >= sw.n) return;
+  const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
+  PosRecord r;
+  r.x = sw.S[(size_t)(F_X + 0) * sw.npad + i];
+  r.y = sw.S[(size_t)(F_X + 1) * sw.npad + i];
+  r.z = sw.S[(size_t)(F_X + 2) * sw.npad + i];
+  r.mass        = P.mass;
+  r.arm_length  = P.arm_length;
+  r.prop_radius = P.prop_radius;
+  rec[i] = r;
+  insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
+}
+
 template <bool LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
@@ -291,15 +302,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   const int       i      = blockIdx.x * 64 + lane;
   const bool      active = i < sw.n;
   if (LISTS) {
-    // the head table of the next rebuild must be empty: wipe it if the previous tick filled it (grid-strided, coalesced)
-    if (ctl[4 + (table_id ^ 1)]) {
-      const uint32_t stride = gridDim.x * 64u;
-      for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
-    }
-    if (!force && ctl[cur] == 0u) {  // wave-uniform: nobody has left its skin since the lists were built
-      if (active) list_tick(sw, rec, nbr, nbr_cnt, i, crash, rebounce);
-      return;
-    }
+    if (!force && ctl[cur] == 0u) return;  // list tick: k_pack_insert has done the work
     nl_n[lane] = 0;
   }
   const long long gi     = my_offset + i;
@@ -591,7 +594,8 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   uint2*         other = w->head[w->cur ^ 1];
   w->cur ^= 1;
   if (rec_is_local_scratch)
-    hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0);
+    hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0,
+                       nullptr, 0u, nullptr, nullptr, 0, 0.0);
   else
     hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
   hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
@@ -635,7 +639,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
   hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce);
   hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
