@@ -255,6 +255,19 @@ public:
     mrs_throw_on_error(mrs_swarm_get_outputs(s_, first, count, out.data()));
     return out;
   }
+  // the same without the host copy: the pointer stays valid until the next getOutputs* call
+  const mrs_uav_output_t* getOutputsView(int first, int count) {
+    const mrs_uav_output_t* v = nullptr;
+    mrs_throw_on_error(mrs_swarm_get_outputs_view(s_, first, count, &v));
+    return v;
+  }
+  // batched subscriber side: pinned rows to fill with setInput payloads (layout of mrs_swarm_set_input), then one commit
+  double* inputStaging(int count, int stride) {
+    double* rows = nullptr;
+    mrs_throw_on_error(mrs_swarm_input_staging(s_, count, stride, &rows));
+    return rows;
+  }
+  void commitInput(int first, int count, int mode, int stride) { mrs_throw_on_error(mrs_swarm_commit_input(s_, first, count, mode, stride)); }
   // the tail of the UavSystemRos constructor (:223-232) for the whole swarm: zero actuators, two makeStep(0.01)
   void warmUp() {
     std::vector<double> zeros((size_t)size() * MRS_MAX_MOTORS, 0.0);

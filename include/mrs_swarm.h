@@ -134,6 +134,14 @@ int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out);
  *   ATTITUDE: R[9] row-major, throttle | TILT_HDG_RATE: tilt[3], heading_rate, throttle
  *   ACCELERATION_HDG(_RATE) / VELOCITY_HDG(_RATE) / POSITION: vec[3], heading(_rate) | INPUT_UNKNOWN: none */
 int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride);
+/* Staged form of mrs_swarm_set_input for hosts that refresh every command each tick (the subscriber callbacks of
+ * src/uav_system_ros.cpp:679-1022, batched): mrs_swarm_input_staging hands out pinned host memory for count rows of `stride`
+ * doubles (row k = the setInput payload of UAV first+k, layouts as above); the caller fills it and mrs_swarm_commit_input sends it
+ * with one asynchronous copy + one unpack kernel — no pageable staging, no per-column copies.  The rows may be refilled after the
+ * next mrs_swarm_input_staging call (which waits for the copy in flight). */
+int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, double** rows);
+int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, int32_t stride);
+
 /* UavSystem::setFeedforward(...) x4 — uav_system.hpp:254-272.  payload: vec[3], heading(_rate) */
 int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride);
 /* UavSystem::applyForce — uav_system.hpp:295; force: count x 3 */
@@ -186,6 +194,9 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out);
 /* publishOdometry + publishIMU + publishRangefinder + publishPoses payloads of UAVs [first, first+count): one pack kernel,
  * one device-to-host copy (src/uav_system_ros.cpp:342-431, src/multirotor_simulator.cpp:365-389) */
 int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out);
+/* the same payloads without the final host copy: *view points into the library's pinned staging buffer and stays valid until the
+ * next mrs_swarm_get_outputs* call on this swarm (publishers fill their messages straight from it) */
+int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_uav_output_t** view);
 
 /* ---- multi-GPU collision exchange (one swarm shard per process/GPU) ---- */
 /* device pointer + byte size of this shard's packed {x,y,z,mass,arm_length,prop_radius} records (48 B/UAV), refreshed by

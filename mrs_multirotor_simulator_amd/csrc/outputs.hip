@@ -156,6 +156,22 @@ __global__ void __launch_bounds__(256) k_timeout_input(SwarmDev sw, int first, i
 
 }  // namespace
 
+// Staged command upload: `rows` holds count x stride doubles in the caller's row layout (one UAV per row, as setInput receives
+// them); element j of every row goes to column `base + j`.  One coalesced read of the rows, `width` coalesced column writes.
+__global__ void __launch_bounds__(256) k_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const size_t np = (size_t)sw.npad;
+  for (int j = 0; j < width; j++) sw.S[(size_t)(base + j) * np + first + k] = rows[(size_t)k * stride + j];
+}
+
+extern "C" hipError_t mrs_launch_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count,
+                                             hipStream_t st) {
+  if (count <= 0 || width <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((count + 255) / 256), dim3(256), 0, st, sw, rows, stride, width, base, first, count);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_timeout_input, dim3((count + 255) / 256), dim3(256), 0, st, sw, first, count);

@@ -35,6 +35,7 @@ extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st,
 extern "C" void mrs_collide_free(CollideWork* w);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
+extern "C" hipError_t mrs_launch_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -239,6 +240,10 @@ struct mrs_swarm {
   mrs_uav_output_t* dOut = nullptr;
   mrs_uav_output_t* hOut = nullptr;
   int32_t           out_cap = 0;
+  // staged command upload: pinned host rows + device copy
+  double* hIn = nullptr;
+  double* dIn = nullptr;
+  int64_t in_cap = 0;  // doubles
   // collision scratch
   PosRecord*   dRec = nullptr;
   CollideWork* cwork = nullptr;
@@ -577,6 +582,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->dRec) (void)hipFree(s->dRec);
   if (s->dOut) (void)hipFree(s->dOut);
   if (s->hOut) (void)hipHostFree(s->hOut);
+  if (s->hIn) (void)hipHostFree(s->hIn);
+  if (s->dIn) (void)hipFree(s->dIn);
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
@@ -1093,14 +1100,10 @@ int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double 
   return modify_params(s, first, count, [&](mrs_model_params_t& p) { p.ground_z = ground_z; });  // :1063-1073
 }
 
-int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {
-  MRS_LOCK(s);
-  int rc = check_range(s, first, count);
-  if (rc) return rc;
-  if (!out) return fail(MRS_ERR_ARG, "null out");
-  if (count == 0) return MRS_OK;
+static int fetch_outputs(mrs_swarm* s, int32_t first, int32_t count) {
   HIPCHK(hipSetDevice(s->device));
-  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
+  if (rc) return rc;
   if (count > s->out_cap) {
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->dOut) HIPCHK(hipFree(s->dOut));
@@ -1112,8 +1115,73 @@ int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_
   HIPCHK(mrs_launch_pack_outputs(s->view(), first, count, s->dOut, s->stream));
   HIPCHK(hipMemcpyAsync(s->hOut, s->dOut, sizeof(mrs_uav_output_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+  return MRS_OK;
+}
+
+int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {
+  MRS_LOCK(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  if (count == 0) return MRS_OK;
+  if ((rc = fetch_outputs(s, first, count))) return rc;
   memcpy(out, s->hOut, sizeof(mrs_uav_output_t) * (size_t)count);
   return MRS_OK;
+}
+
+int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_uav_output_t** view) {
+  MRS_LOCK(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!view) return fail(MRS_ERR_ARG, "null view");
+  *view = nullptr;
+  if (count == 0) return MRS_OK;
+  if ((rc = fetch_outputs(s, first, count))) return rc;
+  *view = s->hOut;
+  return MRS_OK;
+}
+
+int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, double** rows) {
+  MRS_LOCK(s);
+  if (!s || !rows) return fail(MRS_ERR_ARG, "null argument");
+  if (count < 0 || count > s->n || stride < 1 || stride > 16) return fail(MRS_ERR_ARG, "bad staging shape");
+  HIPCHK(hipSetDevice(s->device));
+  const int64_t need = (int64_t)count * stride;
+  HIPCHK(hipStreamSynchronize(s->stream));  // an earlier commit may still be reading the rows
+  if (need > s->in_cap) {
+    if (s->hIn) HIPCHK(hipHostFree(s->hIn));
+    if (s->dIn) HIPCHK(hipFree(s->dIn));
+    s->hIn = nullptr;
+    s->dIn = nullptr;
+    HIPCHK(hipHostMalloc(&s->hIn, sizeof(double) * (size_t)need, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&s->dIn, sizeof(double) * (size_t)need));
+    s->in_cap = need;
+  }
+  *rows = s->hIn;
+  return MRS_OK;
+}
+
+int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, int32_t stride) {
+  MRS_LOCK(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (mode < MRS_ACTUATOR_CMD || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
+  if (count == 0) return MRS_OK;
+  if (!s->hIn || (int64_t)count * stride > s->in_cap) return fail(MRS_ERR_ARG, "no staging rows of this shape (call mrs_swarm_input_staging first)");
+  int width = 4;
+  if (mode == MRS_ACTUATOR_CMD) width = stride < MRS_MAX_MOTORS ? stride : MRS_MAX_MOTORS;
+  if (mode == MRS_ATTITUDE_CMD) width = 10;
+  if (mode == MRS_TILT_HDG_RATE_CMD) width = 5;
+  if (stride < width) return fail(MRS_ERR_ARG, "stride too small for this mode");
+  if (mode == MRS_ACTUATOR_CMD) {
+    for (int k = 0; k < count; k++)
+      if (s->keys[s->uav_type[(size_t)first + k]].mp.n_motors > width) return fail(MRS_ERR_ARG, "actuator payload narrower than n_motors");
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipMemcpyAsync(s->dIn, s->hIn, sizeof(double) * (size_t)count * (size_t)stride, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(mrs_launch_unpack_rows(s->view(), s->dIn, stride, width, F_CMD, first, count, s->stream));
+  track_mode(s, first, count, mode);
+  return flags_update(s, first, count, ~FLAG_MODE_MASK, (uint32_t)mode << FLAG_MODE_SHIFT);
 }
 
 int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds) {

@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
-    "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
+    "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
 _lib = None
@@ -155,6 +155,9 @@ def load_library():
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
+        "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
+        "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
+        "mrs_swarm_commit_input": [vp, i32, i32, i32, i32],
         "mrs_swarm_get_collision_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
@@ -370,6 +373,28 @@ class Swarm:
         assert out.dtype.itemsize == C.sizeof(UavOutput)
         _check(_lib.mrs_swarm_get_outputs(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def get_outputs_view(self, first=0, count=None):
+        """get_outputs without the final host copy: a structured-array VIEW of the library's pinned staging buffer, valid until
+        the next get_outputs* call."""
+        count = self.n - first if count is None else count
+        ptr = C.c_void_p()
+        _check(_lib.mrs_swarm_get_outputs_view(self._h, first, count, C.byref(ptr)))
+        if count == 0:
+            return np.zeros(0, dtype=OUTPUT_DTYPE)
+        buf = (C.c_char * (count * OUTPUT_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=OUTPUT_DTYPE, count=count)
+
+    def input_staging(self, count, stride):
+        """pinned host rows (count x stride doubles) to be filled with setInput payloads and sent by commit_input"""
+        ptr = C.POINTER(C.c_double)()
+        _check(_lib.mrs_swarm_input_staging(self._h, int(count), int(stride), C.byref(ptr)))
+        if count == 0:
+            return np.zeros((0, stride))
+        return np.ctypeslib.as_array(ptr, shape=(int(count), int(stride)))
+
+    def commit_input(self, first, count, mode, stride):
+        _check(_lib.mrs_swarm_commit_input(self._h, int(first), int(count), int(mode), int(stride)))
 
     def get_diag(self):
         d = Diag()

@@ -77,3 +77,39 @@ def test_gpu_outputs_match_oracle(mrs, oracle):
         helpers.assert_close(a[k], b[k], 1e-12, k)
     sub = p.g.get_outputs(1490, 20)
     assert np.array_equal(sub["position"], a["position"][1490:1510]) and np.array_equal(sub["range"], a["range"][1490:1510])
+
+
+@pytest.mark.gpu
+def test_outputs_view_and_staged_input_equal_the_copying_calls(mrs, oracle):
+    """mrs_swarm_get_outputs_view == mrs_swarm_get_outputs; mrs_swarm_input_staging + commit_input == mrs_swarm_set_input, for every
+    payload width, on a sub-range, and re-used across ticks."""
+    import helpers
+    rng = np.random.default_rng(91)
+    n = 333
+    a, b = mrs.Swarm(n), mrs.Swarm(n)
+    pos = rng.uniform(-20, 20, (n, 3)) + [0, 0, 30]
+    for g in (a, b):
+        g.construct(0, n, mrs.model_params("x500", ground_enabled=True, ground_z=0.0), pos, rng.uniform(-3, 3, n) * 0)
+    cases = [(mrs.POSITION_CMD, 4, 4), (mrs.ACTUATOR_CMD, 4, 4), (mrs.ACTUATOR_CMD, 8, 8), (mrs.ATTITUDE_CMD, 10, 10),
+             (mrs.TILT_HDG_RATE_CMD, 5, 7), (mrs.VELOCITY_HDG_CMD, 4, 6)]
+    first, count = 17, 300
+    for tick, (mode, width, stride) in enumerate(cases):
+        payload = rng.uniform(0.3, 0.6, (count, stride))
+        if mode == mrs.ATTITUDE_CMD:
+            payload[:, :9] = helpers.tilted_rotations(rng, count).reshape(count, 9)
+        a.set_input(first, count, mode, payload)
+        rows = b.input_staging(count, stride)
+        rows[:] = payload
+        b.commit_input(first, count, mode, stride)
+        a.step_n(0.001, 5)
+        b.step_n(0.001, 5)
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), f"case {tick}: {k}"
+        oa = a.get_outputs(first, count)
+        ov = b.get_outputs_view(first, count)
+        assert oa.dtype == ov.dtype and oa.shape == ov.shape
+        for f in oa.dtype.names:
+            assert np.array_equal(oa[f], ov[f]), f"case {tick}: output {f}"
+    with pytest.raises(Exception):
+        b.commit_input(0, n, mrs.ATTITUDE_CMD, 4)   # stride too small for the mode
