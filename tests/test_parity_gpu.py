@@ -728,3 +728,34 @@ def test_state_array_beyond_2_GiB_still_addresses_every_column(M, oracle):
     ref = o.get_state()
     for k in ("x", "v", "R", "omega", "motor_rpm"):
         helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"3.2M swarm, first copy vs oracle: {k}")
+
+
+def test_fast_kernel_nan_lane_does_not_disturb_its_wave(M, oracle):
+    """FAST runs the RK4 stages without the per-component NaN guards and repeats a wave's step with them when a lane ends up with a
+    NaN (step_device.inc).  The finite lanes of such a wave must get exactly the bits they get without the NaN neighbour, the NaN
+    lane must be rolled back like the reference does (multirotor_model.hpp:228-233), and the counters must show it."""
+    rng = np.random.default_rng(88)
+    n = 256
+    st = random_state(rng, n, 4)
+    cmd = rng.uniform(0.35, 0.6, (n, 4))
+    sws = []
+    for poison in (False, True):
+        g = M.Swarm(n, arith=M.ARITH_FAST)
+        g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(n))
+        s2 = {k: v.copy() for k, v in st.items()}
+        if poison:
+            s2["v"][5, 1] = np.nan          # wave 0
+            s2["omega"][130, 2] = np.inf    # wave 2: an inf rate makes NaNs inside the stages
+        g.set_state(0, n, s2["x"], s2["v"], s2["R"], s2["omega"], s2["motor_rpm"])
+        g.set_input(0, n, oracle.ACTUATOR_CMD, cmd)
+        g.step_n(DT, 3)
+        sws.append((g.get_state(), g.get_diag()))
+    (a, da), (b, db) = sws
+    clean = np.ones(n, bool)
+    clean[[5, 130]] = False
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        assert np.array_equal(a[k][clean], b[k][clean]), k
+    assert da["nan_rollback"] == 0 and db["nan_rollback"] >= 3
+    # the rolled-back lane keeps its (non-finite) start state for x/v/R/omega; the motor filter still runs (:244-246)
+    assert np.isnan(b["v"][5, 1]) and np.array_equal(b["x"][5], st["x"][5])
+    assert np.array_equal(b["motor_rpm"][5], a["motor_rpm"][5])
