@@ -32,8 +32,10 @@ def pmc_traffic(args, n):
     """HBM-side bytes per launch from the committed rocprofv3 PMC summary of this same command (profiles/), corrected as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950 (confirmed by the calibration rows of that summary for this
     8-B/lane SoA pattern), WRITE_SIZE exact, both x1024.  None when no summary matches the configuration."""
-    path = os.path.join(ROOT, "profiles", f"r01_step_kernel_{n // 1000}k_{args.arith}_summary.json")
-    if args.workload != "actuator" or args.substeps != 1 or not os.path.exists(path):
+    stem = {"actuator": "step_kernel", "position": "position_cascade"}.get(args.workload)
+    size = f"{n // 1000}k" if n < 1_000_000 else f"{n // 1_000_000}M"
+    path = os.path.join(ROOT, "profiles", f"r01_{stem}_{size}_{args.arith}_summary.json")
+    if stem is None or args.substeps != 1 or not os.path.exists(path):
         return None, None
     pmc = json.load(open(path)).get("pmc", {})
     if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:

@@ -2,7 +2,7 @@
 # Produces the rocprofv3 evidence for profiles/ (run on the GPU box through gpurun; outputs under gpurun_out/profile_round).
 # Kernel-trace/stats and every --pmc pass are separate runs (gpurun refuses combined modes).
 set -u
-OUT=gpurun_out/profile_round
+OUT=${PROFILE_OUT:-gpurun_out/profile_round}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 300 --warmup 50 --no-cpu-baseline}"
