@@ -759,3 +759,41 @@ def test_fast_kernel_nan_lane_does_not_disturb_its_wave(M, oracle):
     # the rolled-back lane keeps its (non-finite) start state for x/v/R/omega; the motor filter still runs (:244-246)
     assert np.isnan(b["v"][5, 1]) and np.array_equal(b["x"][5], st["x"][5])
     assert np.array_equal(b["motor_rpm"][5], a["motor_rpm"][5])
+
+
+def test_nan_rollback_inside_a_fused_launch(M, oracle):
+    """A UAV whose step produces a NaN is rolled back to the start of THAT step (multirotor_model.hpp:228-233).  Inside a launch that
+    fuses several sub-steps the state of the launch start is all HBM holds, so the kernel keeps the sub-step's start state itself:
+    a UAV that turns non-finite in the middle of a launch must end exactly where the unfused sequence leaves it."""
+    rng = np.random.default_rng(61)
+    n = 192
+    wild = [7, 70, 130]
+    for arith, tol in ((M.ARITH_LITERAL, RTOL_LITERAL), (M.ARITH_FAST, RTOL_FAST)):
+        st = random_state(rng, n, 4)
+        # body rates of 1e150 rad/s: R grows by ~1e147 per step, R^T R overflows a few steps in -> NaN derivatives -> rollbacks
+        st["omega"][7] = [1e150, 0.0, 0.0]
+        st["omega"][70] = [0.0, 3e151, 1e150]
+        st["omega"][130] = [1e100, 1e100, 1e100]
+        cmd = rng.uniform(0.35, 0.6, (n, 4))
+        runs, diags = [], []
+        for sub in (1, 6, 4):
+            p = Pair(M, n, arith=arith)
+            p.construct(0, n, "x500", ground_enabled=True, ground_z=0.0)
+            p.set_state(0, n, st)
+            p.both("set_input", 0, n, oracle.ACTUATOR_CMD, cmd)
+            p.o.step_n(DT, 12)
+            p.g.step_n(DT, 12, sub)
+            a, b = p.g.get_state(), p.o.get_state()
+            clean = np.ones(n, bool)
+            clean[wild] = False
+            for k in a:  # the oracle comparison leaves the overflowing UAVs out: inf arithmetic is not part of the parity contract
+                helpers.assert_close(a[k][clean], b[k][clean], tol, f"arith {arith}, {sub} sub-steps: {k}")
+            runs.append(a)
+            diags.append(p.g.get_diag()["nan_rollback"])
+        assert diags[0] > 0 and diags[0] == diags[1] == diags[2], diags
+        for r in runs[1:]:
+            for k in runs[0]:
+                if arith == M.ARITH_LITERAL:
+                    assert np.array_equal(runs[0][k], r[k], equal_nan=True), f"literal: fused != unfused in {k}"
+                else:  # FMA contraction differs between the kernel instantiations: last bits only, and only finite lanes compared
+                    helpers.assert_close(runs[0][k][clean], r[k][clean], 1e-11, f"fast: fused vs unfused, {k}")
