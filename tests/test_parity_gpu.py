@@ -95,14 +95,16 @@ def test_feedforward_slots(M, oracle, mode, kinds):
     p.compare(RTOL_LITERAL, f"ff {kinds} mode {mode}")
 
 
-def test_config1_single_uav_trajectory(M, oracle):
+@pytest.mark.parametrize("fast", [False, True])
+def test_config1_single_uav_trajectory(M, oracle, fast):
     """BASELINE config 1: 1 x500, spawn (10,15,0) hdg 3.14, two warm-up steps of 0.01 s, POSITION_CMD (12,13,5,1.0),
-    20 000 steps of 1 ms.  A swarm of one goes through the same kernel."""
-    p = Pair(M, 1)
+    20 000 steps of 1 ms.  A swarm of one goes through the same kernel; both arithmetic flavours stay inside the north-star
+    tolerance over the whole closed-loop flight."""
+    p = Pair(M, 1, arith=M.ARITH_FAST if fast else M.ARITH_LITERAL)
     p.construct(0, 1, "x500", pos=[[10, 15, 0]], heading=[3.14], ground_enabled=True, ground_z=0.0, takeoff_patch_enabled=False)
     p.both("set_input", 0, 1, oracle.ACTUATOR_CMD, [[0.0] * 4])
     p.step(0.01, 2)
-    p.compare(RTOL_LITERAL, "warm-up")
+    p.compare(RTOL_FAST if fast else RTOL_LITERAL, "warm-up")
     p.both("set_input", 0, 1, oracle.POSITION_CMD, [[12, 13, 5, 1.0]])
     for k in range(20):
         p.step(DT, 1000)
