@@ -158,3 +158,95 @@ def test_gpu_spawn_from_config_matches_oracle(mrs, oracle):
     a, b = sw.get_state(), o.get_state()
     for k in b:
         helpers.assert_close(a[k], b[k], helpers.RTOL_LITERAL, k)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the C++ loader of the same files (include/mrs_multirotor_simulator/config_loader.hpp)
+# ------------------------------------------------------------------------------------------------------------------
+def _build_config_loader_test(mrs):
+    import os, subprocess
+    from mrs_multirotor_simulator_amd import swarm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "config_loader_test")
+    libdir = os.path.dirname(swarm.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DMRS_NO_EIGEN", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "config_loader_test.cpp"), "-o", exe, "-L", libdir, "-lmrs_swarm", "-lpthread",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _cpp_loader_output(exe, files, run=False):
+    import subprocess
+    out = subprocess.run([exe] + list(files) + (["--run"] if run else []), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [ln.split() for ln in out.stdout.splitlines()]
+    return {"sim": [r for r in rows if r[0] == "SIM"], "uav": [r for r in rows if r[0] == "UAV"], "params": [r for r in rows if r[0] == "PARAMS"],
+            "pose": [r for r in rows if r[0] == "POSE"]}
+
+
+def _check_cpp_against_python_loader(mrs, files):
+    from mrs_multirotor_simulator_amd import config
+    exe = _build_config_loader_test(mrs)
+    got = _cpp_loader_output(exe, files)
+    cfg = config.load_yaml_files(files)
+    names = list(cfg["uav_names"])
+    assert [r[1] for r in got["uav"]] == names
+    for r, prm, name in zip(got["uav"], got["params"], names):
+        sp = cfg[name]["spawn"]
+        assert r[2] == cfg[name]["type"] and [float(v) for v in r[3:7]] == [float(sp[k]) for k in ("x", "y", "z", "heading")]
+        p = config.model_params_from_config(cfg, cfg[name]["type"])
+        n = p.n_motors
+        want = [n, p.g, p.mass, p.kf, p.km, p.prop_radius, p.arm_length, p.body_height, p.motor_time_constant, p.max_rpm, p.min_rpm,
+                p.air_resistance_coeff, p.ground_enabled, p.ground_z, p.takeoff_patch_enabled, p.J[0], p.J[4], p.J[8]]
+        want += [p.allocation_matrix[rr * 8 + m] for rr in range(4) for m in range(n)]
+        assert [float(v) for v in prm[2:]] == [float(v) for v in want], name  # bit-identical: both go through the library's host arithmetic
+    return got, cfg
+
+
+def test_cpp_config_loader_matches_python_loader(mrs):
+    import os
+    sample = os.path.join(os.path.dirname(__file__), "golden", "sample_config.yaml")
+    got, cfg = _check_cpp_against_python_loader(mrs, [sample])
+    assert got["sim"][0][1:] == ["100", "100", "1", "1", "1", "100", "1", "1"]  # defaults of the shipped simulator file
+
+
+def test_cpp_config_loader_reads_the_reference_config_directory(mrs):
+    """The reference's own parameter files (only present next to a reference checkout): both loaders must agree on every airframe."""
+    import glob, os
+    base = "/root/reference/config"
+    if not os.path.isdir(base):
+        pytest.skip("no reference checkout here")
+    files = [os.path.join(base, "multirotor_simulator.yaml"), os.path.join(base, "uavs.yaml")] + sorted(glob.glob(os.path.join(base, "uavs", "*.yaml"))) + \
+        sorted(glob.glob(os.path.join(base, "controllers", "*.yaml")))
+    got, cfg = _check_cpp_against_python_loader(mrs, files)
+    assert got["sim"][0][1:4] == ["100", "100", "1"] and got["uav"][0][1:3] == ["uav1", "x500"]
+    # every airframe file parses (the uavs.yaml above only instantiates one of them): feed each through a one-UAV fleet
+    import tempfile
+    for f in sorted(glob.glob(os.path.join(base, "uavs", "*.yaml"))):
+        ty = os.path.splitext(os.path.basename(f))[0]
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as t:
+            t.write(f'uav_names: ["u"]\nu:\n  type: "{ty}"\n  spawn: {{x: 0, y: 0, z: 0, heading: 0}}\n')
+        try:
+            _check_cpp_against_python_loader(mrs, files + [t.name])
+        finally:
+            os.unlink(t.name)
+
+
+@pytest.mark.gpu
+def test_cpp_swarm_from_config_matches_python_path(mrs):
+    """constructSwarmFromConfig (C++) == spawn_swarm_from_config (Python): same launches, same bits after 300 commanded steps."""
+    import os
+    import numpy as np
+    from mrs_multirotor_simulator_amd import config
+    sample = os.path.join(os.path.dirname(__file__), "golden", "sample_config.yaml")
+    got = _cpp_loader_output(_build_config_loader_test(mrs), [sample], run=True)
+    cfg = config.load_yaml_files([sample])
+    sw, names = config.spawn_swarm_from_config(cfg, arith=mrs.ARITH_LITERAL)
+    cmd = []
+    for nm in names:
+        sp = cfg[nm]["spawn"]
+        cmd.append([sp["x"] + 1.0, sp["y"] - 1.0, sp["z"] + 2.0, 0.3])
+    sw.set_input(0, len(names), mrs.POSITION_CMD, np.array(cmd))
+    sw.step_n(0.001, 300)
+    x = sw.get_state()["x"]
+    assert np.array_equal(np.array([[float(v) for v in r[2:5]] for r in got["pose"]]), x)

@@ -99,3 +99,29 @@ def test_simulator_over_the_swarm_on_gpu(mrs):
     assert out.returncode == 0, out.stdout + out.stderr
     for tag in ("frozen_without_input", "only_commanded_uavs_move", "timeout_puts_on_hold", "paced"):
         assert f"ok {tag}" in out.stdout, out.stdout
+
+
+def _build_example(mrs):
+    from mrs_multirotor_simulator_amd import swarm
+    exe = os.path.join(ROOT, "tests", "cpp", "standalone_swarm")
+    libdir = os.path.dirname(swarm.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DMRS_NO_EIGEN", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "standalone_swarm.cpp"), "-o", exe, "-L", libdir, "-lmrs_swarm", "-lpthread",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_standalone_example_compiles(mrs):
+    assert os.path.exists(_build_example(mrs))
+
+
+@pytest.mark.gpu
+def test_standalone_example_runs(mrs):
+    """examples/standalone_swarm.cpp on the sample parameter file: config -> swarm -> paced loop; the first UAV climbs towards its goal."""
+    out = subprocess.run([_build_example(mrs), "1.2", os.path.join(ROOT, "tests", "golden", "sample_config.yaml")], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("t_sim")]
+    assert len(lines) == 2 and "3 UAVs" in out.stdout
+    z = float(lines[-1].split("(")[1].split(")")[0].split(",")[2])
+    assert z > 0.6, out.stdout  # spawned at 0.5 m, goal 5 m higher
