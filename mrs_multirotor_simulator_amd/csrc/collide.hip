@@ -222,11 +222,9 @@ __device__ __forceinline__ PosRecord current_record(const SwarmDev& sw, const Po
   return o;
 }
 
-__device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* rec, const uint32_t* nbr, const uint32_t* nbr_cnt, int i, int crash,
+__device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* rec, const uint32_t* nbr, uint32_t cnt, uint32_t j0, int i, int crash,
                                           double rebounce) {
-  const size_t   np  = (size_t)sw.npad;
-  const uint32_t cnt = nbr_cnt[i];
-  const uint32_t j0  = nbr[i];  // first list row, fetched together with the count (always a valid index, stale beyond cnt)
+  const size_t np = (size_t)sw.npad;  // cnt / j0: the UAV's list length and first row (always a valid index, stale beyond cnt)
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   if (cnt) {
@@ -255,6 +253,11 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
                               double rebounce) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (LISTS) {
+    // issued before the control words are looked at: on a list tick (the common case) these are the first links of the
+    // dependent load chain, and the addresses are valid on a rebuild tick too
+    const int      ic  = i < sw.n ? i : sw.n - 1;
+    const uint32_t cnt = nbr_cnt[ic], j0 = nbr[ic];
+    asm volatile("" ::: "memory");
     const bool rebuild = force || ctl[cur] != 0u;
     if (i == 0) {
       ctl[cur ^ 1]     = 0u;  // the next tick's flag: the step kernel (or this tick's query, on list overflow) raises it
@@ -267,7 +270,7 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
       for (uint32_t t = (uint32_t)i; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
     }
     if (!rebuild) {  // wave-uniform: nobody has left its skin since the lists were built — this kernel IS the collision tick
-      if (i < sw.n) list_tick(sw, rec, nbr, nbr_cnt, i, crash, rebounce);
+      if (i < sw.n) list_tick(sw, rec, nbr, cnt, j0, i, crash, rebounce);
       return;
     }
   }
