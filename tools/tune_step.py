@@ -15,8 +15,8 @@ VARIANTS = {
     "default": "",
     "w1": "-DMRS_WAVES_PER_SIMD=1",
     "w3": "-DMRS_WAVES_PER_SIMD=3",
-    "unroll1": "-DMRS_STAGE_UNROLL=1",
-    "unroll2": "-DMRS_STAGE_UNROLL=2",
+    "unroll1": "-DMRS_SU=1",
+    "unroll2": "-DMRS_SU=2",
     "maxilp": "-mllvm -amdgpu-sched-strategy=max-ilp",
     "maxilp_w1": "-mllvm -amdgpu-sched-strategy=max-ilp -DMRS_WAVES_PER_SIMD=1",
     "memclause": "-mllvm -amdgpu-sched-strategy=max-memory-clause",
