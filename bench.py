@@ -195,7 +195,7 @@ def main():
         npad = (n + 63) // 64 * 64
         kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
         if 86 * npad * 8 < 2 ** 32:
-            kernel_name += "_buf" + ("_w3" if (args.substeps == 1 and npad // 64 > 2048) else "")
+            kernel_name += "_buf" + ("_w3" if (args.substeps == 1 and npad // 64 > 2048 and args.arith == "fast") else "")
         kernel_name += "_" + args.arith
         out = {
             "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
