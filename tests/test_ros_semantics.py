@@ -250,3 +250,21 @@ def test_cpp_swarm_from_config_matches_python_path(mrs):
     sw.step_n(0.001, 300)
     x = sw.get_state()["x"]
     assert np.array_equal(np.array([[float(v) for v in r[2:5]] for r in got["pose"]]), x)
+
+
+def test_builtin_airframes_equal_the_reference_parameter_files(mrs):
+    """mrs_multirotor_simulator_amd/airframes.py (used by tests and bench) against config/uavs/*.yaml of a reference checkout."""
+    import glob, os
+    from mrs_multirotor_simulator_amd import airframes, config
+    base = "/root/reference/config"
+    if not os.path.isdir(base):
+        pytest.skip("no reference checkout here")
+    files = [os.path.join(base, "multirotor_simulator.yaml")] + sorted(glob.glob(os.path.join(base, "uavs", "*.yaml")))
+    cfg = config.load_yaml_files(files)
+    names = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(base, "uavs", "*.yaml")))
+    assert names == sorted(airframes.AIRFRAMES)
+    for name in names:
+        ref = config.model_params_from_config(cfg, name)
+        got = airframes.model_params(name, ground_enabled=bool(ref.ground_enabled), ground_z=ref.ground_z,
+                                     takeoff_patch_enabled=bool(ref.takeoff_patch_enabled))
+        assert bytes(ref) == bytes(got), name
