@@ -268,3 +268,20 @@ def test_builtin_airframes_equal_the_reference_parameter_files(mrs):
         got = airframes.model_params(name, ground_enabled=bool(ref.ground_enabled), ground_z=ref.ground_z,
                                      takeoff_patch_enabled=bool(ref.takeoff_patch_enabled))
         assert bytes(ref) == bytes(got), name
+
+
+def test_default_controller_gains_equal_the_reference_parameter_files(mrs):
+    """The defaults of the five set_*_params calls (= the reference headers' defaults) against config/controllers/*.yaml."""
+    import glob, inspect, os
+    from mrs_multirotor_simulator_amd import config
+    base = "/root/reference/config/controllers"
+    if not os.path.isdir(base):
+        pytest.skip("no reference checkout here")
+    ref = config.load_yaml_files(sorted(glob.glob(os.path.join(base, "*.yaml"))))
+    assert ref["mixer"] == config.CONTROLLER_DEFAULTS["mixer"]
+    for blk, meth in (("rate_controller", "set_rate_params"), ("attitude_controller", "set_attitude_params"),
+                      ("velocity_controller", "set_velocity_params"), ("position_controller", "set_position_params")):
+        assert {k: float(v) for k, v in ref[blk].items()} == config.CONTROLLER_DEFAULTS[blk], blk
+        sig = inspect.signature(getattr(mrs.Swarm, meth))
+        defaults = {k: p.default for k, p in sig.parameters.items() if p.default is not inspect.Parameter.empty}
+        assert defaults == config.CONTROLLER_DEFAULTS[blk], meth
