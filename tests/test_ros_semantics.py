@@ -285,3 +285,23 @@ def test_default_controller_gains_equal_the_reference_parameter_files(mrs):
         sig = inspect.signature(getattr(mrs.Swarm, meth))
         defaults = {k: p.default for k, p in sig.parameters.items() if p.default is not inspect.Parameter.empty}
         assert defaults == config.CONTROLLER_DEFAULTS[blk], meth
+
+
+def test_cpp_config_loader_reads_the_400_uav_launch_layering(mrs):
+    """BASELINE config 2's own parameter file (tmux/standalone_400_uavs/custom_configs/simulator.yaml) layered over the defaults the
+    way the launch file does: 400 UAVs, both loaders agree, and the spawn grid is the one the config-2 parity test uses."""
+    import glob, os
+    import numpy as np
+    base = "/root/reference/config"
+    custom = "/root/reference/tmux/standalone_400_uavs/custom_configs/simulator.yaml"
+    if not os.path.isfile(custom):
+        pytest.skip("no reference checkout here")
+    files = [os.path.join(base, "multirotor_simulator.yaml"), os.path.join(base, "uavs.yaml")] + sorted(glob.glob(os.path.join(base, "uavs", "*.yaml"))) + \
+        sorted(glob.glob(os.path.join(base, "controllers", "*.yaml"))) + [custom]
+    got, cfg = _check_cpp_against_python_loader(mrs, files)
+    assert len(got["uav"]) == 400 and {r[2] for r in got["uav"]} == {"f550"}
+    assert got["sim"][0][4:7] == ["1", "0", "100"]  # collisions enabled, crash off (the custom file), rebounce 100
+    xy = np.array([[float(r[3]), float(r[4])] for r in got["uav"]])
+    gx, gy = np.meshgrid(np.arange(20) * 4.0, np.arange(20) * 4.0, indexing="ij")
+    want = np.stack([gx.ravel(), gy.ravel()], axis=1)
+    assert sorted(map(tuple, xy - xy.min(axis=0))) == sorted(map(tuple, want))  # a 20 x 20 grid with 4 m pitch
