@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Long differential run: a dense, moving swarm with elastic collisions, position commands that change, occasional crashes and
+holds — product (tick_n) vs oracle (step + handle_collisions per tick), compared every `chunk` ticks.
+usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers
+from helpers import Pair
+import mrs_multirotor_simulator_amd as M
+from oracle import oracle_swarm as O
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+fast = len(sys.argv) > 3 and sys.argv[3] == "fast"
+rtol = 1e-6 if fast else 1e-10
+DT, chunk = 0.001, 250
+rng = np.random.default_rng(2026)
+side = (30.0 * n) ** (1.0 / 3.0)   # 30 m^3 per UAV: plenty of contacts
+p = Pair(M, n, arith=M.ARITH_FAST if fast else M.ARITH_LITERAL)
+pos = rng.uniform(0, side, (n, 3)) + [0, 0, 1.0]
+p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n), ground_enabled=True, ground_z=0.0)
+p.both("set_input", 0, n, O.POSITION_CMD, np.concatenate([pos + rng.uniform(-6, 6, (n, 3)), rng.uniform(-3, 3, (n, 1))], axis=1))
+t0 = time.time()
+worst = 0.0
+for c in range(ticks // chunk):
+    if c % 2 == 1:  # new goals for a third of the swarm, a few crashes, a few UAVs on hold
+        a = int(rng.integers(0, n - n // 3))
+        x = p.o.get_state(a, n // 3)["x"]
+        p.both("set_input", a, n // 3, O.POSITION_CMD, np.concatenate([x + rng.uniform(-8, 8, (n // 3, 3)), rng.uniform(-3, 3, (n // 3, 1))], axis=1))
+        p.both("crash", int(rng.integers(0, n - 5)), 5)
+        p.both("set_hold", int(rng.integers(0, n - 50)), 50, bool(c % 4 == 1))
+    for _ in range(chunk):
+        p.o.step_n(DT, 1, 16)
+        p.o.handle_collisions(True, False, 100.0)
+    p.g.tick_n(DT, chunk, True, False, 100.0)
+    e = p.compare(rtol, f"after {(c + 1) * chunk} ticks")
+    helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), max(rtol, 1e-11), "forces")
+    assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
+    worst = max(worst, e)
+    touched = int((np.abs(p.o.get_external_force()).sum(axis=1) > 0).sum())
+    print(f"tick {(c + 1) * chunk:6d}: max rel err {e:.2e}, {touched} UAVs in contact, collision stats {p.g.collision_stats()}, {time.time() - t0:.0f} s", flush=True)
+print("SOAK OK", n, "UAVs", ticks, "ticks", "fast" if fast else "literal", "worst", worst)
