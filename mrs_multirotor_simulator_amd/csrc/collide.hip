@@ -44,7 +44,8 @@ constexpr double SKIN          = 0.5;         // neighbour lists: how far apart 
 constexpr double INV_CELL_WIDE = 1.0 / 2.25;  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508
 constexpr double LIST_R2       = 4.9821;      // > (sqrt(3) + SKIN)^2 = 4.98205...
 constexpr double POS_LIMIT     = 1.0e9;       // |coordinate| beyond this (or non-finite) never collides here
-constexpr int    LIST_CAP      = 8;           // listed neighbours per UAV (0.7 expected at 64 m^3 per UAV)
+constexpr int    LIST_CAP      = 24;          // listed neighbours per UAV (0.7 expected at 64 m^3 per UAV, 4.6 at 10 m^3: P(> 24) ~ 1e-11;
+                                              // with 8, one UAV in 10^4 overflowed at 30 m^3 per UAV and kept a 100 k swarm searching)
 
 struct Cell { int x, y, z; bool ok; };
 
