@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long differential run: a dense, moving swarm with elastic collisions, position commands that change, occasional crashes and
 holds — product (tick_n) vs oracle (step + handle_collisions per tick), compared every `chunk` ticks.
-usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast]"""
+usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast] [m^3 per UAV]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,8 @@ fast = len(sys.argv) > 3 and sys.argv[3] == "fast"
 rtol = 1e-6 if fast else 1e-10
 DT, chunk = 0.001, 250
 rng = np.random.default_rng(2026)
-side = (30.0 * n) ** (1.0 / 3.0)   # 30 m^3 per UAV: plenty of contacts
+vol = float(sys.argv[4]) if len(sys.argv) > 4 else 30.0  # m^3 per UAV (30: plenty of contacts)
+side = (vol * n) ** (1.0 / 3.0)
 p = Pair(M, n, arith=M.ARITH_FAST if fast else M.ARITH_LITERAL)
 pos = rng.uniform(0, side, (n, 3)) + [0, 0, 1.0]
 p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n), ground_enabled=True, ground_z=0.0)
