@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--uavs", type=int, default=100_000, help="UAVs per GPU")
+    ap.add_argument("--volume-per-uav", type=float, default=64.0, help="collision workloads: m^3 of air space per UAV")
     ap.add_argument("--workload", choices=["actuator", "position", "position+collisions"], default="actuator")
     ap.add_argument("--arith", choices=["literal", "fast"], default="fast",
                     help="fast: FMA + rsqrt arithmetic (within 1e-6 of the reference, the production flavour); literal: reference op order")
@@ -58,14 +59,14 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(n, workload, seed):
+def make_inputs(n, workload, seed, volume_per_uav=64.0):
     import helpers
     rng = np.random.default_rng(seed)
     if workload == "actuator":
         st = helpers.random_state(rng, n, 4)
         cmd = rng.uniform(0.35, 0.60, (n, 4))
     else:
-        side = (64.0 * n) ** (1.0 / 3.0)  # 64 m^3 per UAV (BASELINE config 4), cube-shaped box
+        side = (volume_per_uav * n) ** (1.0 / 3.0)  # 64 m^3 per UAV by default (BASELINE config 4)
         st = helpers.random_state(rng, n, 4, tilted=True)
         st["x"] = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
         cmd = np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
@@ -141,7 +142,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     n = args.uavs
-    st, cmd = make_inputs(n, args.workload, seed=3 + rank)
+    st, cmd = make_inputs(n, args.workload, seed=3 + rank, volume_per_uav=args.volume_per_uav)
     sw = M.Swarm(n, device=local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
     sw.construct(0, n, M.model_params("x500", ground_enabled=True))
     sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])

@@ -190,16 +190,18 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
 // Wave-cooperative query, one single-wave workgroup per 64 local UAVs.
 //   A  every lane fetches its 27 bucket heads (independent loads, one memory round trip); a head whose tag is not the probed
 //      cell's and that has no chain is dropped on the spot (~2 candidates per UAV remain on a 64 m^3/UAV swarm)
-//   B  the (owner lane, probed cell, candidate) triples of the whole wave are compacted into an LDS list (wave prefix sum)
-//   C  the list is processed 64 x U entries at a time with uniform control flow — this is what removes the 27-way divergent
+//   B  the (owner lane, probed cell, candidate) triples of the whole wave are compacted into an LDS list (wave prefix sum),
+//      PAIR_CAP at a time
+//   C  the list is swept 64 x U entries at a time with uniform control flow — this is what removes the 27-way divergent
 //      walk in which some lane always had a non-empty bucket and every iteration paid a full memory latency.  An entry
-//      of a chained bucket also fetches its `next` link and appends it to the list; qualifying partners go to a small
-//      per-owner hit list (LDS atomics)
-//   D  owners order their (rare) hits by index and accumulate; overflow of either list falls back to query_lane_sweeps
+//      of a chained bucket also fetches its `next` link, which takes over the entry's slot for the next sweep; qualifying
+//      partners go to a small per-owner hit list (LDS atomics)
+//   D  owners order their (rare) hits by index and accumulate; a UAV with more hits than its list holds falls back to
+//      query_lane_sweeps
 #ifndef MRS_TABLE_FACTOR
 #define MRS_TABLE_FACTOR 4
 #endif
-constexpr int      PAIR_CAP  = 1024;
+constexpr int      PAIR_CAP  = 1024;  // bucket heads taken into the LDS list per pass
 constexpr int      HIT_CAP   = 6;
 constexpr uint32_t META_WALK = 0x10000u;  // pair meta: owner lane | probed cell q << 8 | WALK (follow the `next` link)
 
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   __shared__ uint32_t  pair_m[PAIR_CAP];   // meta
   __shared__ uint32_t  hit_j[64][HIT_CAP];
   __shared__ uint32_t  hit_n[64];
-  __shared__ uint32_t  list_total, list_overflow, hit_overflow;  // two flags: each is only ever set, never downgraded
+  __shared__ uint32_t  list_total, hit_overflow;
   __shared__ uint32_t  nl_j[LISTS ? 64 : 1][LISTS ? LIST_CAP : 1];  // neighbour lists under construction
   __shared__ uint32_t  nl_n[LISTS ? 64 : 1];
 
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   me_s[lane]   = me;
   me_cell[lane] = make_int4(c.x, c.y, c.z, 0);
   hit_n[lane]  = 0;
-  if (lane == 0) list_overflow = hit_overflow = 0;
+  if (lane == 0) hit_overflow = 0;
 
 #ifdef MRS_QUERY_CLOCK
   const unsigned long long t0 = clock_fence(0u);
@@ -359,95 +361,92 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
     const uint32_t o = __shfl_up(inc, off, 64);
     if (lane >= off) inc += o;
   }
-  if (lane == 63) list_total = inc;
-  uint32_t slot = inc - tc;
-#pragma unroll
-  for (int q = 0; q < 27; q++) {
-    if (info[q].x != 0u) {
-      if (slot < (uint32_t)PAIR_CAP) {  // 64 x 27 heads can exceed the list: the total is checked below
-        pair_e[slot] = make_uint2(info[q].x, info[q].y & ~CHAIN_BIT);
-        pair_m[slot] = (uint32_t)lane | ((uint32_t)q << 8) | ((info[q].y & CHAIN_BIT) ? META_WALK : 0u);
-      }
-      slot++;
-    }
-  }
+  __shared__ uint32_t heads_total;
+  if (lane == 63) heads_total = inc;
   __syncthreads();
-#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 2
-  if (pair_e[lane].x == 0xFFFFFFFFu) sw.F[i] = 1;
-  return;
-#endif
+  const uint32_t n_heads = heads_total;
 #ifdef MRS_QUERY_CLOCK
-  const unsigned long long tB = clock_fence(pair_e[lane].x);
+  const unsigned long long tB = clock_fence(n_heads);
 #endif
-  // C: uniform sweep over the list, U independent entries per lane and iteration so that their loads overlap
+  // B + C run once per window of PAIR_CAP heads: a dense neighbourhood takes several passes instead of dropping to the
+  // per-lane sweeps.  A chained bucket is walked IN PLACE: after a member has been evaluated its list slot takes the next
+  // member of the chain, and the window is swept again until every chain has ended — no appends, so nothing can overflow.
   constexpr int U = 4;
-  uint32_t total = list_total;
-  if (total > PAIR_CAP) {
-    list_overflow = 1;
-    total         = 0;
-  }
-  for (uint32_t base = 0; base < total;) {
-    uint2    pe[U], nx[U];
-    uint32_t pm[U];
-    bool     live[U];
+  for (uint32_t wbase = 0; wbase < n_heads; wbase += PAIR_CAP) {
+    const uint32_t wn = n_heads - wbase < (uint32_t)PAIR_CAP ? n_heads - wbase : (uint32_t)PAIR_CAP;
+    uint32_t slot = inc - tc;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t p = base + u * 64 + lane;
-      pe[u] = pair_e[p < total ? p : 0u];
-      pm[u] = p < total ? pair_m[p] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) nx[u] = (pm[u] & META_WALK) ? next[pe[u].x - 1u] : make_uint2(0u, 0u);
-    // tag filter: only members of exactly the probed cell survive (false positives of the 31-bit tag are caught by the exact
-    // cell comparison below)
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const uint32_t p = base + u * 64 + lane;
-      live[u] = false;
-      if (p < total) {
-        const int  ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
-        const int4 mc = me_cell[ow];
-        live[u] = pe[u].y == (cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) & ~CHAIN_BIT) &&
-                  (long long)pe[u].x - 1 != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
+    for (int q = 0; q < 27; q++) {
+      if (info[q].x != 0u) {
+        if (slot >= wbase && slot - wbase < (uint32_t)PAIR_CAP) {
+          pair_e[slot - wbase] = make_uint2(info[q].x, info[q].y & ~CHAIN_BIT);
+          pair_m[slot - wbase] = (uint32_t)lane | ((uint32_t)q << 8) | ((info[q].y & CHAIN_BIT) ? META_WALK : 0u);
+        }
+        slot++;
       }
     }
+    __syncthreads();
+    // C: uniform sweeps over the window, U independent entries per lane and iteration so that their loads overlap
+    for (bool more = true; more;) {
+      if (lane == 0) list_total = 0;  // "some chain goes on" flag of this sweep
+      __syncthreads();
+      for (uint32_t base = 0; base < wn; base += 64 * U) {
+        uint2    pe[U], nx[U];
+        uint32_t pm[U];
+        bool     live[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (nx[u].x != 0u) {  // the chain goes on: its next member joins the list
-        const uint32_t k = atomicAdd(&list_total, 1u);
-        if (k < PAIR_CAP) {
-          pair_e[k] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
-          pair_m[k] = pm[u];
-        } else {
-          list_overflow = 1;
+        for (int u = 0; u < U; u++) {
+          const uint32_t p = base + u * 64 + lane;
+          pe[u] = p < wn ? pair_e[p] : make_uint2(0u, 0u);  // .x == 0: the slot's chain has ended
+          pm[u] = p < wn ? pair_m[p] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) nx[u] = (pe[u].x != 0u && (pm[u] & META_WALK)) ? next[pe[u].x - 1u] : make_uint2(0u, 0u);
+        // tag filter: only members of exactly the probed cell survive (false positives of the 31-bit tag are caught by the
+        // exact cell comparison below)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          live[u] = false;
+          if (pe[u].x != 0u) {
+            const int  ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
+            const int4 mc = me_cell[ow];
+            live[u] = pe[u].y == (cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) & ~CHAIN_BIT) &&
+                      (long long)pe[u].x - 1 != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t p = base + u * 64 + lane;
+          if (p < wn && pe[u].x != 0u) {  // the slot moves on to the next member of its chain (or ends)
+            pair_e[p] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
+            if (nx[u].x != 0u) list_total = 1u;
+          }
+          if (!live[u]) continue;
+          const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
+          const int4      mc = me_cell[ow];
+          const PosRecord o  = rec[pe[u].x - 1u];
+          const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
+          if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
+          const PosRecord m = me_s[ow];
+          if (LISTS) {
+            const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
+            if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
+              const uint32_t k = atomicAdd(&nl_n[ow], 1u);
+              if (k < (uint32_t)LIST_CAP) nl_j[ow][k] = pe[u].x - 1u;
+            }
+          }
+          if (!qualifies(m, o, crash)) continue;
+          const uint32_t k = atomicAdd(&hit_n[ow], 1u);
+          if (k < HIT_CAP)
+            hit_j[ow][k] = pe[u].x - 1u;
+          else
+            hit_overflow = 1;
         }
       }
-      if (!live[u]) continue;
-      const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
-      const int4      mc = me_cell[ow];
-      const PosRecord o  = rec[pe[u].x - 1u];
-      const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
-      if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
-      const PosRecord m = me_s[ow];
-      if (LISTS) {
-        const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
-        if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
-          const uint32_t k = atomicAdd(&nl_n[ow], 1u);
-          if (k < (uint32_t)LIST_CAP) nl_j[ow][k] = pe[u].x - 1u;
-        }
-      }
-      if (!qualifies(m, o, crash)) continue;
-      const uint32_t k = atomicAdd(&hit_n[ow], 1u);
-      if (k < HIT_CAP)
-        hit_j[ow][k] = pe[u].x - 1u;
-      else
-        hit_overflow = 1;
+      __syncthreads();
+      more = list_total != 0u;
+      __syncthreads();  // nobody resets the flag before everybody has read it
     }
-    base = (base + 64 * U < total) ? base + 64 * U : total;  // entries appended meanwhile start at the old total
-    __syncthreads();  // appended entries and the new total are visible
-    total = list_total;
-    if (list_overflow) total = 0;
-    __syncthreads();  // nobody appends before everybody has read the total
   }
   __syncthreads();
 #if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 3
@@ -461,7 +460,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   if (active && c.ok) {
-    if (list_overflow || (hit_overflow && hit_n[lane] > HIT_CAP)) {  // dense neighbourhood: the reference path
+    if (hit_overflow && hit_n[lane] > HIT_CAP) {  // more qualifying partners than the hit list holds: the reference path
       query_lane_sweeps<LISTS>(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
     } else {
       const uint32_t nh = hit_n[lane];
@@ -481,10 +480,11 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   }
   if (LISTS) {
     // the lists of this wave: ascending, like the order partners are consumed in.  An incomplete list (more than LIST_CAP
-    // neighbours, or the dense fallback above, which does not collect them) keeps the next tick in rebuild mode.
+    // neighbours) keeps the next tick in rebuild mode.
     uint32_t cnt = nl_n[lane];
-    if (list_overflow || cnt > (uint32_t)LIST_CAP) {
+    if (cnt > (uint32_t)LIST_CAP) {
       ctl[cur ^ 1] = 1u;
+      atomicAdd(&ctl[6], 1u);  // statistics: lanes over the list capacity
       cnt = 0;
     }
     if (active) {
@@ -609,6 +609,14 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
 
 // Single-GPU tick with neighbour lists.  force_rebuild: the host changed positions or airframe constants since the last call.
 // number of list rebuilds so far (device counter; synchronises the stream)
+// debugging aid (not part of the public header): the eight control words
+extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8) {
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  if (!w || !w->ctl) return hipSuccess;
+  CK(hipMemcpyAsync(out8, w->ctl, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out) {
   *out = 0;
   if (!w || !w->ctl) return hipSuccess;

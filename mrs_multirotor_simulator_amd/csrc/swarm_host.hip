@@ -32,6 +32,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
 extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st);
 extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
+extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void mrs_collide_free(CollideWork* w);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
@@ -1192,6 +1193,15 @@ int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_r
   HIPCHK(mrs_collide_rebuilds(s->cwork, s->stream, &rb));
   if (n_ticks) *n_ticks = s->collision_ticks;
   if (n_rebuilds) *n_rebuilds = s->use_lists ? (int64_t)rb : s->collision_ticks;
+  return MRS_OK;
+}
+
+// debugging aid for tools/ (deliberately not declared in include/mrs_swarm.h)
+int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8) {
+  MRS_LOCK(s);
+  if (!s || !out8) return fail(MRS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(mrs_collide_debug_words(s->cwork, s->stream, out8));
   return MRS_OK;
 }
 
