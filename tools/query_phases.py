@@ -15,6 +15,7 @@ lib = "/tmp/qph/libmrs_swarm_clock.so"
 subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, o] + [os.path.join(OBJ, f) for f in
                       ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "swarm_host.o")])
 os.environ["MRS_SWARM_LIB"] = lib
+os.environ["MRS_NEIGHBOUR_LISTS"] = "0"  # time the search itself on every call
 import mrs_multirotor_simulator_amd as M
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 rng = np.random.default_rng(4)
