@@ -290,6 +290,124 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
+// The 27 bucket heads of a UAV's neighbourhood, filtered: .x != 0 marks an entry for the work list (a head of the probed cell,
+// or any head of a chained bucket), .y = its tag with CHAIN_BIT kept for chained buckets.  Returns the number of entries.
+// Unconditional loads from always-valid addresses: a load under a divergent branch is waited for at the join, which would
+// serialise 27 memory round trips.
+__device__ __forceinline__ uint32_t load_heads(const Cell& c, uint32_t mask, const uint2* head, uint2 (&info)[27]) {
+  uint32_t tc = 0;
+#pragma unroll
+  for (int q = 0; q < 27; q++) info[q] = head[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
+#pragma unroll
+  for (int q = 0; q < 27; q++) {
+    const uint32_t tg    = cell_tag(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1) & ~CHAIN_BIT;
+    const bool     chain = (info[q].y & CHAIN_BIT) != 0u;
+    const bool     take  = c.ok && info[q].x != 0u && (chain || info[q].y == tg);
+    info[q].y = (info[q].y & ~CHAIN_BIT);
+    if (!take) info[q].x = 0u;
+    if (take && chain) info[q].y |= CHAIN_BIT;
+    tc += take ? 1u : 0u;
+  }
+  return tc;
+}
+
+// entries [wbase, wbase + PAIR_CAP) of the wave's head sequence -> LDS work list (first_slot: this lane's position in the sequence)
+__device__ __forceinline__ void fill_window(const uint2 (&info)[27], uint32_t first_slot, uint32_t wbase, int lane, uint2* pair_e, uint32_t* pair_m) {
+  uint32_t slot = first_slot;
+#pragma unroll
+  for (int q = 0; q < 27; q++) {
+    if (info[q].x != 0u) {
+      if (slot >= wbase && slot - wbase < (uint32_t)PAIR_CAP) {
+        pair_e[slot - wbase] = make_uint2(info[q].x, info[q].y & ~CHAIN_BIT);
+        pair_m[slot - wbase] = (uint32_t)lane | ((uint32_t)q << 8) | ((info[q].y & CHAIN_BIT) ? META_WALK : 0u);
+      }
+      slot++;
+    }
+  }
+}
+
+struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
+  uint2*      pair_e;
+  uint32_t*   pair_m;
+  PosRecord*  me_s;
+  int4*       me_cell;
+  uint32_t*   hit_j;   // [64][HIT_CAP]
+  uint32_t*   hit_n;
+  uint32_t*   nl_j;    // [64][LIST_CAP]
+  uint32_t*   nl_n;
+  uint32_t*   more_flag;
+  uint32_t*   hit_overflow;
+};
+
+// C: uniform sweeps over one window of the work list, U independent entries per lane and iteration so that their loads overlap.
+// A chained bucket is walked IN PLACE: after a member has been evaluated its slot takes the next member of the chain, and the
+// window is swept again until every chain has ended — no appends, so nothing can overflow.
+template <bool LISTS>
+__device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int lane, const PosRecord* rec, const uint2* next, long long wave_first,
+                                             int crash) {
+  constexpr int U = 4;
+  for (bool more = true; more;) {
+    if (lane == 0) *L.more_flag = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < wn; base += 64 * U) {
+      uint2    pe[U], nx[U];
+      uint32_t pm[U];
+      bool     live[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t p = base + u * 64 + lane;
+        pe[u] = p < wn ? L.pair_e[p] : make_uint2(0u, 0u);  // .x == 0: the slot's chain has ended
+        pm[u] = p < wn ? L.pair_m[p] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) nx[u] = (pe[u].x != 0u && (pm[u] & META_WALK)) ? next[pe[u].x - 1u] : make_uint2(0u, 0u);
+      // tag filter: only members of exactly the probed cell survive (false positives of the 31-bit tag are caught by the exact
+      // cell comparison below)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        live[u] = false;
+        if (pe[u].x != 0u) {
+          const int  ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
+          const int4 mc = L.me_cell[ow];
+          live[u] = pe[u].y == (cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) & ~CHAIN_BIT) &&
+                    (long long)pe[u].x - 1 != wave_first + ow;  // idx == i, src/multirotor_simulator.cpp:335
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t p = base + u * 64 + lane;
+        if (p < wn && pe[u].x != 0u) {  // the slot moves on to the next member of its chain (or ends)
+          L.pair_e[p] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
+          if (nx[u].x != 0u) *L.more_flag = 1u;
+        }
+        if (!live[u]) continue;
+        const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
+        const int4      mc = L.me_cell[ow];
+        const PosRecord o  = rec[pe[u].x - 1u];
+        const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
+        if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
+        const PosRecord m = L.me_s[ow];
+        if (LISTS) {
+          const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
+          if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
+            const uint32_t k = atomicAdd(&L.nl_n[ow], 1u);
+            if (k < (uint32_t)LIST_CAP) L.nl_j[ow * LIST_CAP + k] = pe[u].x - 1u;
+          }
+        }
+        if (!qualifies(m, o, crash)) continue;
+        const uint32_t k = atomicAdd(&L.hit_n[ow], 1u);
+        if (k < HIT_CAP)
+          L.hit_j[ow * HIT_CAP + k] = pe[u].x - 1u;
+        else
+          *L.hit_overflow = 1;
+      }
+    }
+    __syncthreads();
+    more = *L.more_flag != 0u;
+    __syncthreads();  // nobody resets the flag before everybody has read it
+  }
+}
+
 template <bool LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
@@ -322,130 +440,58 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   hit_n[lane]  = 0;
   if (lane == 0) hit_overflow = 0;
 
+  __shared__ uint32_t heads_total;
 #ifdef MRS_QUERY_CLOCK
   const unsigned long long t0 = clock_fence(0u);
+  unsigned long long       tA = 0, tB = 0;
 #endif
-  // A: bucket heads.  Unconditional loads from always-valid addresses: a load under a divergent branch is waited for at
-  // the join, which would serialise 27 memory round trips.
-  uint2    info[27];
-  uint32_t tc = 0;
-#pragma unroll
-  for (int q = 0; q < 27; q++) info[q] = head[bucket_of(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1, mask)];
-  // this tick's table has been read: wipe the other one for the next tick (grid-strided, coalesced)
-  if (!LISTS) {
-    const uint32_t stride = gridDim.x * 64u;
-    for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
-  }
-#pragma unroll
-  for (int q = 0; q < 27; q++) {
-    const uint32_t tg    = cell_tag(c.x + q / 9 - 1, c.y + (q / 3) % 3 - 1, c.z + q % 3 - 1) & ~CHAIN_BIT;
-    const bool     chain = (info[q].y & CHAIN_BIT) != 0u;
-    const bool     take  = c.ok && info[q].x != 0u && (chain || info[q].y == tg);
-    info[q].y = (info[q].y & ~CHAIN_BIT);
-    if (!take) info[q].x = 0u;
-    // .x != 0: entry goes to the list;  keep the chain flag in the top bit of .y again for phase B
-    if (take && chain) info[q].y |= CHAIN_BIT;
-    tc += take ? 1u : 0u;
-  }
-#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 1
-  if (tc == 0xFFFFFFFFu) sw.F[i] = tc;
-  return;
-#endif
-#ifdef MRS_QUERY_CLOCK
-  const unsigned long long tA = clock_fence(tc);
-#endif
-  // B: wave prefix sum -> slots in the pair list
-  uint32_t inc = tc;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
-  __shared__ uint32_t heads_total;
-  if (lane == 63) heads_total = inc;
-  __syncthreads();
-  const uint32_t n_heads = heads_total;
-#ifdef MRS_QUERY_CLOCK
-  const unsigned long long tB = clock_fence(n_heads);
-#endif
-  // B + C run once per window of PAIR_CAP heads: a dense neighbourhood takes several passes instead of dropping to the
-  // per-lane sweeps.  A chained bucket is walked IN PLACE: after a member has been evaluated its list slot takes the next
-  // member of the chain, and the window is swept again until every chain has ended — no appends, so nothing can overflow.
-  constexpr int U = 4;
-  for (uint32_t wbase = 0; wbase < n_heads; wbase += PAIR_CAP) {
-    const uint32_t wn = n_heads - wbase < (uint32_t)PAIR_CAP ? n_heads - wbase : (uint32_t)PAIR_CAP;
-    uint32_t slot = inc - tc;
-#pragma unroll
-    for (int q = 0; q < 27; q++) {
-      if (info[q].x != 0u) {
-        if (slot >= wbase && slot - wbase < (uint32_t)PAIR_CAP) {
-          pair_e[slot - wbase] = make_uint2(info[q].x, info[q].y & ~CHAIN_BIT);
-          pair_m[slot - wbase] = (uint32_t)lane | ((uint32_t)q << 8) | ((info[q].y & CHAIN_BIT) ? META_WALK : 0u);
-        }
-        slot++;
-      }
+  // A: bucket heads
+  uint32_t first_slot, n_heads;
+  {
+    uint2          info[27];
+    const uint32_t tc = load_heads(c, mask, head, info);
+    // this tick's table has been read by this wave's probes: wipe the other one for the next tick (grid-strided, coalesced)
+    if (!LISTS) {
+      const uint32_t stride = gridDim.x * 64u;
+      for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
     }
+#if defined(MRS_QUERY_STOP) && MRS_QUERY_STOP == 1
+    if (tc == 0xFFFFFFFFu) sw.F[i] = tc;
+    return;
+#endif
+#ifdef MRS_QUERY_CLOCK
+    tA = clock_fence(tc);
+#endif
+    // B: wave prefix sum -> slots in the work list
+    uint32_t inc = tc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) heads_total = inc;
+    first_slot = inc - tc;
     __syncthreads();
-    // C: uniform sweeps over the window, U independent entries per lane and iteration so that their loads overlap
-    for (bool more = true; more;) {
-      if (lane == 0) list_total = 0;  // "some chain goes on" flag of this sweep
+    n_heads = heads_total;
+    if (n_heads <= (uint32_t)PAIR_CAP) fill_window(info, first_slot, 0u, lane, pair_e, pair_m);  // the usual case: one window, `info` dies here
+  }
+#ifdef MRS_QUERY_CLOCK
+  tB = clock_fence(n_heads);
+#endif
+  const QueryLds lds{pair_e, pair_m, me_s, me_cell, &hit_j[0][0], hit_n, &nl_j[0][0], nl_n, &list_total, &hit_overflow};
+  const long long wave_first = my_offset + (long long)blockIdx.x * 64;
+  if (n_heads <= (uint32_t)PAIR_CAP) {
+    __syncthreads();
+    sweep_window<LISTS>(lds, n_heads, lane, rec, next, wave_first, crash);
+  } else {
+    // dense neighbourhood: more heads than the list holds — windows of PAIR_CAP, the heads are probed again per window
+    // (cheaper than keeping 27 head words per lane alive across the sweeps of the usual case)
+    for (uint32_t wbase = 0; wbase < n_heads; wbase += PAIR_CAP) {
+      uint2 info[27];
+      load_heads(c, mask, head, info);
+      fill_window(info, first_slot, wbase, lane, pair_e, pair_m);
       __syncthreads();
-      for (uint32_t base = 0; base < wn; base += 64 * U) {
-        uint2    pe[U], nx[U];
-        uint32_t pm[U];
-        bool     live[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t p = base + u * 64 + lane;
-          pe[u] = p < wn ? pair_e[p] : make_uint2(0u, 0u);  // .x == 0: the slot's chain has ended
-          pm[u] = p < wn ? pair_m[p] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) nx[u] = (pe[u].x != 0u && (pm[u] & META_WALK)) ? next[pe[u].x - 1u] : make_uint2(0u, 0u);
-        // tag filter: only members of exactly the probed cell survive (false positives of the 31-bit tag are caught by the
-        // exact cell comparison below)
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          live[u] = false;
-          if (pe[u].x != 0u) {
-            const int  ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
-            const int4 mc = me_cell[ow];
-            live[u] = pe[u].y == (cell_tag(mc.x + q / 9 - 1, mc.y + (q / 3) % 3 - 1, mc.z + q % 3 - 1) & ~CHAIN_BIT) &&
-                      (long long)pe[u].x - 1 != my_offset + blockIdx.x * 64 + ow;  // idx == i, src/multirotor_simulator.cpp:335
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t p = base + u * 64 + lane;
-          if (p < wn && pe[u].x != 0u) {  // the slot moves on to the next member of its chain (or ends)
-            pair_e[p] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
-            if (nx[u].x != 0u) list_total = 1u;
-          }
-          if (!live[u]) continue;
-          const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
-          const int4      mc = me_cell[ow];
-          const PosRecord o  = rec[pe[u].x - 1u];
-          const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
-          if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
-          const PosRecord m = me_s[ow];
-          if (LISTS) {
-            const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
-            if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
-              const uint32_t k = atomicAdd(&nl_n[ow], 1u);
-              if (k < (uint32_t)LIST_CAP) nl_j[ow][k] = pe[u].x - 1u;
-            }
-          }
-          if (!qualifies(m, o, crash)) continue;
-          const uint32_t k = atomicAdd(&hit_n[ow], 1u);
-          if (k < HIT_CAP)
-            hit_j[ow][k] = pe[u].x - 1u;
-          else
-            hit_overflow = 1;
-        }
-      }
-      __syncthreads();
-      more = list_total != 0u;
-      __syncthreads();  // nobody resets the flag before everybody has read it
+      sweep_window<LISTS>(lds, n_heads - wbase < (uint32_t)PAIR_CAP ? n_heads - wbase : (uint32_t)PAIR_CAP, lane, rec, next, wave_first, crash);
     }
   }
   __syncthreads();
