@@ -57,7 +57,7 @@ def test_random_call_sequences_match_oracle(mrs, oracle, seed, fast, fleet):
     p.both("set_input", 0, n, oracle.POSITION_CMD, payload(rng, 10, n, pos))
     ops = 0
     for it in range(70):
-        op = rng.integers(0, 15)
+        op = rng.integers(0, 18)
         first, count = rng_range(rng, n)
         x = p.o.get_state(first, count)["x"]
         if op <= 2:
@@ -96,12 +96,38 @@ def test_random_call_sequences_match_oracle(mrs, oracle, seed, fast, fleet):
         elif op == 13:
             crash = bool(rng.integers(0, 4) == 0)
             p.both("handle_collisions", not crash or bool(rng.integers(0, 2)), crash, 100.0)
-        else:
+        elif op == 14:
             k = int(rng.integers(1, 8))
             for _ in range(k):
                 p.o.step(DT)
                 p.o.handle_collisions(True, False, 60.0)
             p.g.tick_n(DT, k, True, False, 60.0)
+        elif op == 15:  # the staged upload path against the plain one
+            mode = int(rng.integers(1, 11))
+            pl = payload(rng, mode, count, x)
+            p.o.set_input(first, count, mode, pl)
+            rows = p.g.input_staging(count, pl.shape[1])
+            rows[:] = pl
+            p.g.commit_input(first, count, mode, pl.shape[1])
+        elif op == 16:  # publisher payloads
+            a, b = p.g.get_outputs_view(first, count), p.o.get_outputs(first, count)
+            for f in a.dtype.names:
+                av, bv = a[f].copy(), b[f].copy()
+                if f == "range" and fast:
+                    # acos(R22) of a level UAV is NaN or 0 depending on the last bit of R22 (the reference's formula, kept):
+                    # FAST states differ from the oracle's in exactly those bits
+                    both = np.isfinite(av) & np.isfinite(bv)
+                    av, bv = av[both], bv[both]
+                helpers.assert_close(av, bv, max(rtol, 1e-9), f"seed {seed}: output {f}")
+        else:  # UavSystem::setParams with another airframe of the same motor count (the reference keeps motor_rpm's size, :374-377)
+            for uav in range(first, first + min(count, 5)):
+                nm = p.o.get_params(uav).n_motors
+                frame = {4: ("x500", "t650", "a300", "f450"), 6: ("f550",), 8: ("naki",)}[nm]
+                po = helpers.oracle_params(frame[int(rng.integers(0, len(frame)))], ground_enabled=True, ground_z=0.0)
+                p.o.set_params(uav, 1, po)
+                p.g.set_params(uav, 1, helpers.to_product_params(mrs, po))
+                xs = p.o.get_state(uav, 1)["x"]
+                p.both("set_input", uav, 1, oracle.POSITION_CMD, payload(rng, 10, 1, xs))
         ops += 1
         if it % 5 == 4:
             p.step(DT, 2)
