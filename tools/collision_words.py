@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Prints the collision pass's device control words (skin flags, search counter, overflow statistics) for a sparse and a dense swarm."""
 import sys, os, ctypes as C
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, helpers
 import mrs_multirotor_simulator_amd as M
 from mrs_multirotor_simulator_amd import swarm as sw_mod
