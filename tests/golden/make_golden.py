@@ -94,8 +94,67 @@ def oracle_trajectories():
     np.savez_compressed(os.path.join(HERE, "oracle_trajectories.npz"), **out)
 
 
+def all_modes_payload(rng, mode, x, n_motors):
+    """one setInput payload of `mode` (layouts of mrs_swarm.h), padded to 10 doubles"""
+    import helpers
+    if mode == O.ACTUATOR_CMD:
+        pl = rng.uniform(0.35, 0.65, n_motors)
+    elif mode == O.CONTROL_GROUP_CMD:
+        pl = np.concatenate([rng.uniform(-0.15, 0.15, 3), rng.uniform(0.4, 0.6, 1)])
+    elif mode == O.ATTITUDE_RATE_CMD:
+        pl = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(0.4, 0.6, 1)])
+    elif mode == O.ATTITUDE_CMD:
+        pl = np.concatenate([helpers.tilted_rotations(rng, 1).ravel(), rng.uniform(0.4, 0.6, 1)])
+    elif mode == O.TILT_HDG_RATE_CMD:
+        pl = np.concatenate([rng.normal(0, 0.2, 3) + [0, 0, 1], rng.uniform(-1, 1, 1), rng.uniform(0.4, 0.6, 1)])
+    elif mode in (O.ACCELERATION_HDG_RATE_CMD, O.ACCELERATION_HDG_CMD):
+        pl = np.concatenate([rng.uniform(-2, 2, 3), rng.uniform(-1, 1, 1)])
+    elif mode in (O.VELOCITY_HDG_RATE_CMD, O.VELOCITY_HDG_CMD):
+        pl = np.concatenate([rng.uniform(-3, 3, 3), rng.uniform(-1, 1, 1)])
+    else:
+        pl = np.concatenate([x + rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 1)])
+    return np.pad(pl, (0, 10 - len(pl)))
+
+
+def all_modes():
+    """every input mode (ACTUATOR_CMD ... POSITION_CMD) x airframes x500 / f550 / naki (4, 6, 8 motors),
+    150 steps of 1 ms from tilted random states with the ground plane on; one feed-forward slot on a third of the UAVs."""
+    import helpers
+    rng = np.random.default_rng(310)
+    names = ["x500", "f550", "naki"]
+    modes = list(range(O.ACTUATOR_CMD, O.POSITION_CMD + 1))
+    n = len(names) * len(modes)
+    s = O.OracleSwarm(n)
+    st0 = helpers.random_state(rng, n, 8, box=20.0, zlo=1.0, zhi=20.0, tilted=True)
+    frames, mode_of, payloads, ff_kind, ff_payload = [], [], [], [], []
+    for i in range(n):
+        af, mode = names[i % 3], modes[i // 3]
+        po = helpers.oracle_params(af, ground_enabled=True, ground_z=0.0)
+        s.construct(i, 1, po, [st0["x"][i]], [0.0])
+        for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+            getattr(s, nm)(i, 1)
+        st0["motor_rpm"][i, po.n_motors:] = 0.0
+        frames.append(af); mode_of.append(mode)
+    s.set_state(0, n, st0["x"], st0["v"], st0["R"], st0["omega"], st0["motor_rpm"])
+    for i in range(n):
+        pl = all_modes_payload(rng, mode_of[i], st0["x"][i], s.get_params(i).n_motors)
+        s.set_input(i, 1, mode_of[i], pl[None, :])
+        payloads.append(pl)
+        kind = int(rng.integers(0, 4)) if i % 3 == 0 else -1
+        ffp = np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.2, 0.2, 1)])
+        if kind >= 0:
+            s.set_feedforward(i, 1, kind, ffp[None, :])
+        ff_kind.append(kind); ff_payload.append(ffp)
+    s.step_n(0.001, 150)
+    st = s.get_state()
+    np.savez_compressed(os.path.join(HERE, "all_modes_trajectories.npz"), frames=np.array(frames), modes=np.array(mode_of), payloads=np.array(payloads),
+                        ff_kind=np.array(ff_kind), ff_payload=np.array(ff_payload), x0=st0["x"], v0=st0["v"], R0=st0["R"], w0=st0["omega"],
+                        rpm0=st0["motor_rpm"], x=st["x"], v=st["v"], R=st["R"], w=st["omega"], rpm=st["motor_rpm"], imu=s.get_imu(), pid=s.get_pid())
+
+
 if __name__ == "__main__":
     nanoflann_sets()
     oracle_trajectories()
+    all_modes()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -94,3 +94,44 @@ def test_gpu_mixed_swarm_against_frozen_oracle_vectors(mrs, arith, rtol):
     for k, key in (("x", "mixed_x"), ("v", "mixed_v"), ("R", "mixed_R"), ("omega", "mixed_w"), ("motor_rpm", "mixed_rpm")):
         helpers.assert_close(st[k], g[key], rtol, key)
     helpers.assert_close(s.get_imu(), g["mixed_imu"], rtol * 10, "imu")
+
+
+def _run_all_modes(make_swarm, params_of, g):
+    """replays tests/golden/all_modes_trajectories.npz on an oracle or product swarm: inputs from the fixture only"""
+    n = len(g["modes"])
+    s = make_swarm(n)
+    for i in range(n):
+        s.construct(i, 1, params_of(str(g["frames"][i])), [g["x0"][i]], [0.0])
+        for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
+            getattr(s, nm)(i, 1)
+    s.set_state(0, n, g["x0"], g["v0"], g["R0"], g["w0"], g["rpm0"])
+    for i in range(n):
+        s.set_input(i, 1, int(g["modes"][i]), g["payloads"][i][None, :])
+        if int(g["ff_kind"][i]) >= 0:
+            s.set_feedforward(i, 1, int(g["ff_kind"][i]), g["ff_payload"][i][None, :])
+    s.step_n(0.001, 150)
+    return s
+
+
+def test_oracle_all_modes_regression(oracle):
+    """every input mode x {x500, f550, naki}: the oracle against its own frozen vectors (SURVEY 7, step 2 iv)"""
+    g = np.load(os.path.join(G, "all_modes_trajectories.npz"))
+    assert sorted(set(g["modes"].tolist())) == list(range(oracle.ACTUATOR_CMD, oracle.POSITION_CMD + 1)) and set(g["frames"].tolist()) == {"x500", "f550", "naki"}
+    s = _run_all_modes(oracle.OracleSwarm, lambda f: helpers.oracle_params(f, ground_enabled=True, ground_z=0.0), g)
+    st = s.get_state()
+    for k, key in (("x", "x"), ("v", "v"), ("R", "R"), ("omega", "w"), ("motor_rpm", "rpm")):
+        helpers.assert_close(st[k], g[key], 1e-12, key)
+    helpers.assert_close(s.get_pid(), g["pid"], 1e-12, "pid")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith,rtol", [(0, 1e-10), (1, 1e-6)])
+def test_gpu_all_modes_against_frozen_oracle_vectors(mrs, arith, rtol):
+    """every input mode x {4, 6, 8 motors} x feed-forward slots, 150 steps — inputs and expected outputs from the fixture only"""
+    g = np.load(os.path.join(G, "all_modes_trajectories.npz"))
+    s = _run_all_modes(lambda n: mrs.Swarm(n, arith=arith), lambda f: mrs.model_params(f, ground_enabled=True, ground_z=0.0), g)
+    st = s.get_state()
+    for k, key in (("x", "x"), ("v", "v"), ("R", "R"), ("omega", "w"), ("motor_rpm", "rpm")):
+        helpers.assert_close(st[k], g[key], rtol, key)
+    helpers.assert_close(s.get_imu(), g["imu"], rtol * 10, "imu")
+    helpers.assert_close(s.get_pid(), g["pid"], rtol * 100, "pid")
