@@ -198,6 +198,12 @@ def main():
         if 86 * npad * 8 < 2 ** 32:
             kernel_name += "_buf" + ("_w3" if (args.substeps == 1 and npad // 64 > 2048 and args.arith == "fast") else "")
         kernel_name += "_" + args.arith
+        # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
+        launches_per_step = 1
+        if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-args.steps // args.substeps) >= 4:
+            launches_per_step = 2
+        if traffic is not None:
+            traffic *= launches_per_step  # the PMC summary is per dispatch; `achieved` and `traffic` are both per step
         out = {
             "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -211,7 +217,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name if not coll
                          else "whole tick: " + kernel_name + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
-                         "method": "one hipEvent pair around the timed region on the swarm's stream: elapsed / launches (inter-launch gaps included)"},
+                         "concurrent_launches_per_step": launches_per_step,
+                         "method": "one hipEvent pair around the timed region on the swarm's stream (the second stream is joined before the closing "
+                                   "event): elapsed / steps, inter-launch gaps included; with two concurrent half-swarm launches per step `achieved` "
+                                   "is the bytes of both over that time, and each launch lasts about one step period (rocprofv3 per-dispatch average)"},
         }
         if coll:
             out["roofline"]["note"] = "per-kernel times of the tick: profiles/r01_collision_tick_100k_kernel_stats.csv"

@@ -799,3 +799,34 @@ def test_nan_rollback_inside_a_fused_launch(M, oracle):
                     assert np.array_equal(runs[0][k], r[k], equal_nan=True), f"literal: fused != unfused in {k}"
                 else:  # FMA contraction differs between the kernel instantiations: last bits only, and only finite lanes compared
                     helpers.assert_close(runs[0][k][clean], r[k][clean], 1e-11, f"fast: fused vs unfused, {k}")
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_two_stream_step_runs_equal_single_stream_ones(M, oracle, fast, monkeypatch):
+    """A run of steps is issued as two half-swarm launches per step on two streams (swarm_host.hip); same kernels, same blocks:
+    the results must be bit-identical to the single-stream order, also when other calls are interleaved between the runs."""
+    rng = np.random.default_rng(97)
+    n = 70_001  # 1094 blocks: above the split threshold, odd block count, ragged tail
+    st = random_state(rng, n, 4, tilted=True)
+    goals = np.concatenate([st["x"] + rng.uniform(-3, 3, (n, 3)), rng.uniform(-3, 3, (n, 1))], axis=1)
+    act = rng.uniform(0.35, 0.6, (n // 2, 4))
+    results = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("MRS_SPLIT_STREAMS", split)
+        g = M.Swarm(n, arith=M.ARITH_FAST if fast else M.ARITH_LITERAL)
+        g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(n))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        g.set_input(0, n, oracle.POSITION_CMD, goals)
+        g.step_n(DT, 12)
+        g.set_input(0, n // 2, oracle.ACTUATOR_CMD, act)     # ordered after the run on both streams
+        g.apply_force(n - 100, 100, rng.normal(0, 2, (100, 3)) * 0 + 1.5)
+        g.step_n(DT, 9)
+        g.step_n(DT, 8, 2)                                   # fused sub-steps, four launches
+        g.handle_collisions(True, False, 100.0)
+        g.step_n(DT, 5)
+        s = g.get_state()
+        s["pid"], s["imu"], s["force"] = g.get_pid(), g.get_imu(), g.get_external_force()
+        results.append(s)
+        del g
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), k
