@@ -163,21 +163,28 @@ def main():
         else:
             sw.step_n(DT, k, args.substeps)
 
-    def barrier():
-        sw.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+    def sync_local():
         sw.synchronize()
         torch.cuda.synchronize()
 
+    def barrier():
+        sync_local()
+        if use_dist:
+            dist.barrier()
+        sync_local()
+
     run(args.warmup)
     barrier()
+    if use_dist:
+        barrier()  # the first RCCL barrier of a process sets up its communicator (milliseconds): keep that out of the start skew
     sw.set_profiling(0 if sharded is not None else 1)  # one hipEvent pair around the timed region, on the swarm's stream
     t0 = time.perf_counter()
     run(args.steps)
-    barrier()
+    # closing bracket: every rank's K steps are complete at its own synchronize — that instant ends ITS interval; the barrier that
+    # follows (an RCCL kernel + host round trip of ~1-2 ms, not part of the workload) and the MAX over ranks close the job's interval
+    sync_local()
     el = time.perf_counter() - t0
+    barrier()
     kern_ms, n_launch = sw.last_step_kernel_ms() if sharded is None else (el / args.steps * 1e3, args.steps)
     sw.set_profiling(0)
     if use_dist:

@@ -563,7 +563,15 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (s->npad == 0) s->npad = 64;
   s->device = device_id;
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  {
+    // The runtime maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) round-robin; once other
+    // libraries in the process (torch, RCCL) have created theirs, two default-priority streams of ours can end up on the same
+    // queue and their launches serialise.  Streams of different priority classes never share a queue.
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (const char* e = getenv("MRS_STREAM2_PRIORITY")) greatest = atoi(e);
+    HIPCHK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, greatest));
+  }
   HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
