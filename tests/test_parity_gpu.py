@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI, via mrs_multirotor_simulator_amd.Swarm) against the
 CPU oracle on identical seeded inputs.  Tolerance of BASELINE.json's north_star: state L-inf <= 1e-6 relative (FP64);
 the LITERAL kernel is additionally held to 1e-11 (it repeats the reference's operation order without FMA contraction)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -588,7 +590,8 @@ def test_neighbour_lists_are_reused_and_rebuilt_with_identical_results(M, oracle
     assert touched > 100
     ticks, rebuilds = p.g.collision_stats()
     assert ticks == 300
-    assert 3 <= rebuilds <= 100, f"{rebuilds} neighbour searches in {ticks} ticks"
+    if os.environ.get("MRS_NEIGHBOUR_LISTS", "1") != "0":  # (the tuning switch that searches on every tick)
+        assert 3 <= rebuilds <= 100, f"{rebuilds} neighbour searches in {ticks} ticks"
 
 
 def test_neighbour_lists_follow_host_writes(M, oracle):
