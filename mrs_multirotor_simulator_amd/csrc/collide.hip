@@ -290,6 +290,76 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
+// ---- neighbour lists over GATHERED records (multi-GPU ticks): every rank holds the current records of all UAVs after the
+// all-gather, so the skin test, the rebuild decision and the list tick are local to the rank — ranks may rebuild on different ticks.
+__device__ __forceinline__ bool record_usable(const PosRecord& r) { return cell_of<true>(r.x, r.y, r.z).ok; }
+
+// flag (ctl[cur]) raised when any record has left its skin since this rank's last rebuild, appeared / disappeared (NaN padding
+// and non-finite positions are "absent"), or changed its airframe constants
+__global__ void k_skin_gathered(const PosRecord* rec, const PosRecord* rec_build, long long n_total, uint32_t* ctl, int cur, double lim2) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) ctl[cur ^ 1] = 0u;  // the next tick's flag (this tick's query raises it on list overflow)
+  if (j >= n_total) return;
+  const PosRecord c = rec[j], b = rec_build[j];
+  const bool      uc = record_usable(c), ub = record_usable(b);
+  bool            moved = uc != ub;
+  if (uc && ub) {
+    const double d0 = c.x - b.x, d1 = c.y - b.y, d2 = c.z - b.z;
+    moved = !((d0 * d0 + d1 * d1) + d2 * d2 <= lim2) || c.mass != b.mass || c.arm_length != b.arm_length || c.prop_radius != b.prop_radius;
+  }
+  if (moved) ctl[cur] = 1u;
+}
+
+__device__ __forceinline__ void list_tick_gathered(const SwarmDev& sw, const PosRecord* rec, long long my_offset, const uint32_t* nbr, uint32_t cnt,
+                                                   uint32_t j0, int i, int crash, double rebounce) {
+  const size_t np = (size_t)sw.npad;
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  bool   crashed = false;
+  if (cnt) {
+    const PosRecord me = rec[my_offset + i];
+    PosRecord       o  = rec[j0];
+    if (record_usable(me)) {
+      for (uint32_t k = 0;;) {
+        if (record_usable(o) && qualifies(me, o, crash)) apply_partner(me, o, crash, rebounce, fx, fy, fz, crashed);
+        if (++k >= cnt) break;
+        o = rec[nbr[(size_t)k * sw.n + i]];
+      }
+    }
+  }
+  sw.S[(size_t)(F_FEXT + 0) * np + i] = fx;
+  sw.S[(size_t)(F_FEXT + 1) * np + i] = fy;
+  sw.S[(size_t)(F_FEXT + 2) * np + i] = fz;
+  if (crashed) sw.F[i] |= FLAG_CRASHED;
+}
+
+// gathered records, lists on: list tick for the rank's own UAVs, or (rebuild) insert of ALL records + a copy of them as the
+// reference of the next skin tests
+__global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRecord* rec_build, long long n_total, long long my_offset, uint32_t mask,
+                                        uint2* head, uint2* next, uint32_t* ctl, int cur, int force, int table_id, uint2* head_to_clear,
+                                        uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash, double rebounce) {
+  const long long j  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int       ic = j < sw.n ? (int)j : sw.n - 1;
+  const uint32_t  cnt = nbr_cnt[ic], j0 = nbr[ic];
+  asm volatile("" ::: "memory");
+  const bool rebuild = force || ctl[cur] != 0u;
+  if (j == 0) {
+    ctl[4 + table_id] = rebuild ? 1u : 0u;
+    if (rebuild) ctl[2] += 1u;
+  }
+  if (ctl[4 + (table_id ^ 1)]) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = (uint32_t)j; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
+  }
+  if (!rebuild) {
+    if (j < sw.n) list_tick_gathered(sw, rec, my_offset, nbr, cnt, j0, (int)j, crash, rebounce);
+    return;
+  }
+  if (j >= n_total) return;
+  const PosRecord r = rec[j];
+  rec_build[j]      = r;
+  insert_uav(j, cell_of<true>(r.x, r.y, r.z), mask, head, next);
+}
+
 // The 27 bucket heads of a UAV's neighbourhood, filtered: .x != 0 marks an entry for the work list (a head of the probed cell,
 // or any head of a chained bucket), .y = its tag with CHAIN_BIT kept for chained buckets.  Returns the number of entries.
 // Unconditional loads from always-valid addresses: a load under a divergent branch is waited for at the join, which would
@@ -570,11 +640,17 @@ struct CollideWork {
   uint32_t * nbr = nullptr, *nbr_cnt = nullptr, *ctl = nullptr;
   int        fcur = 0;             // which of ctl[0..1] the next tick reads
   bool       lists_live = false;   // rec_build / nbr describe this swarm as of some earlier tick
+  PosRecord* g_rec_build = nullptr;  // gathered mode: all records as of this rank's last rebuild
+  long long  g_cap = 0;
+  bool       g_lists_live = false;
 };
 
 static void free_work(CollideWork* w) {
   (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
-  (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl);
+  (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
+  w->g_rec_build = nullptr;
+  w->g_cap = 0;
+  w->g_lists_live = false;
   w->head[0] = w->head[1] = w->next = nullptr;
   w->rec_build = nullptr;
   w->nbr = w->nbr_cnt = w->ctl = nullptr;
@@ -638,6 +714,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   CollideWork* w = *work;
   CK(ensure_tables(w, n_total, st));
   w->lists_live = false;  // the step kernel stops testing; a later list tick starts with a rebuild
+  w->g_lists_live = false;
   const uint32_t T = w->cap_T, mask = T - 1;  // a larger table from an earlier call is still valid (both are empty between ticks)
   const unsigned gN   = (unsigned)((n_total + 255) / 256);
   uint2*         head = w->head[w->cur];
@@ -675,11 +752,12 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   CollideWork*    w = *work;
   const long long n = sw.n;
   CK(ensure_tables(w, n, st));
-  if (!w->rec_build) {
-    CK(hipMalloc(&w->rec_build, sizeof(PosRecord) * (size_t)w->cap_n));
+  if (!w->rec_build) CK(hipMalloc(&w->rec_build, sizeof(PosRecord) * (size_t)w->cap_n));
+  if (!w->nbr) {
     CK(hipMalloc(&w->nbr, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n));
     CK(hipMalloc(&w->nbr_cnt, sizeof(uint32_t) * (size_t)w->cap_n));
     CK(hipMemsetAsync(w->nbr, 0, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n, st));  // rows beyond a UAV's count are read (not used)
+    CK(hipMemsetAsync(w->nbr_cnt, 0, sizeof(uint32_t) * (size_t)w->cap_n, st));
     CK(hipMalloc(&w->ctl, sizeof(uint32_t) * 8));  // [0..1] skin flags, [2] rebuild counter, [4..5] "head table t holds entries"
     CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
     w->fcur = 0;
@@ -702,5 +780,53 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
   w->lists_live = true;
+  w->g_lists_live = false;
+  return hipGetLastError();
+}
+
+// Multi-GPU tick with neighbour lists: `rec` = the gathered current records of all ranks (NaN padding included).
+extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
+                                                     int crash, double rebounce, hipStream_t st) {
+  if (!*work) *work = new CollideWork();
+  CollideWork* w = *work;
+  CK(ensure_tables(w, n_total, st));
+  if (!w->nbr) {
+    CK(hipMalloc(&w->nbr, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n));
+    CK(hipMalloc(&w->nbr_cnt, sizeof(uint32_t) * (size_t)w->cap_n));
+    CK(hipMemsetAsync(w->nbr, 0, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n, st));
+    CK(hipMemsetAsync(w->nbr_cnt, 0, sizeof(uint32_t) * (size_t)w->cap_n, st));
+    CK(hipMalloc(&w->ctl, sizeof(uint32_t) * 8));
+    CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
+  }
+  if (n_total > w->g_cap) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->g_rec_build);
+    CK(hipMalloc(&w->g_rec_build, sizeof(PosRecord) * (size_t)n_total));
+    w->g_cap        = n_total;
+    w->g_lists_live = false;
+  }
+  if (!w->g_lists_live) {  // first gathered list tick, or other modes came in between: empty tables and flags, rebuild
+    CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * (size_t)w->cap_T, st));
+    CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * (size_t)w->cap_T, st));
+    CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
+    CK(hipMemsetAsync(w->g_rec_build, 0xFF, sizeof(PosRecord) * (size_t)w->g_cap, st));  // NaN records
+    w->fcur = 0;
+  }
+  const int      force = w->g_lists_live ? 0 : 1;
+  const uint32_t T = w->cap_T, mask = T - 1;
+  const int      tid  = w->cur;
+  uint2*         head = w->head[tid];
+  uint2*         other = w->head[tid ^ 1];
+  w->cur ^= 1;
+  const unsigned gN = (unsigned)((n_total + 255) / 256);
+  const double   lim2 = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  hipLaunchKernelGGL(k_skin_gathered, dim3(gN), dim3(256), 0, st, rec, w->g_rec_build, n_total, w->ctl, w->fcur, lim2);
+  hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce);
+  hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
+                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
+  w->fcur ^= 1;
+  w->g_lists_live = true;
+  w->lists_live   = false;  // the local-mode skin hook of the step kernel is off
   return hipGetLastError();
 }

@@ -30,6 +30,8 @@ struct CollideWork;
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                       int crash, double rebounce, int rec_is_local_scratch, hipStream_t st);
 extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st);
+extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
+                                                     int crash, double rebounce, hipStream_t st);
 extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
@@ -971,7 +973,12 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
   if (s->n == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   s->fext_active = true;
-  HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, 0, s->stream));
+  s->collision_ticks++;
+  s->nbr_dirty = true;  // a later single-GPU tick starts from a rebuild
+  if (s->use_lists)
+    HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, s->stream));
+  else
+    HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, 0, s->stream));
   return MRS_OK;
 }
 

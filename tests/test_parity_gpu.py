@@ -833,3 +833,61 @@ def test_two_stream_step_runs_equal_single_stream_ones(M, oracle, fast, monkeypa
         del g
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), k
+
+
+def test_gathered_collisions_reuse_neighbour_lists_over_many_ticks(M, oracle):
+    """The multi-GPU collision path on two virtual shards of one GPU, 200 ticks of a moving swarm: per tick every shard steps,
+    packs its records into the (NaN-padded) gathered buffer and collides against it.  The shards keep neighbour lists over the
+    gathered records between searches; forces, crash flags and states must follow the single-swarm oracle, and most ticks must not
+    search."""
+    import torch
+    from mrs_multirotor_simulator_amd.sharded import max_shard, shard_range
+    rng = np.random.default_rng(123)
+    n_total, world = 3001, 2
+    side = (64.0 * n_total) ** (1.0 / 3.0)
+    pos = rng.uniform(0, side, (n_total, 3)) + [0, 0, 30]
+    pos[:200] = pos[200:400] + rng.normal(0, 0.3, (200, 3))
+    st = helpers.random_state(rng, n_total, 4, tilted=True)
+    st["x"] = pos
+    st["v"] = rng.normal(0, 5.0, (n_total, 3))
+    cmd = rng.uniform(0.4, 0.55, (n_total, 4))
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    o = oracle.OracleSwarm(n_total)
+    o.construct(0, n_total, po, pos, np.zeros(n_total))
+    o.set_state(0, n_total, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, n_total, oracle.ACTUATOR_CMD, cmd)
+    n_max = max_shard(n_total, world)
+    recv = torch.full((world * n_max, 6), float("nan"), dtype=torch.float64, device="cuda")
+    shards = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, world, r)
+        g = M.Swarm(hi - lo)
+        g.construct(0, hi - lo, helpers.to_product_params(M, po), pos[lo:hi], np.zeros(hi - lo))
+        g.set_state(0, hi - lo, st["x"][lo:hi], st["v"][lo:hi], st["R"][lo:hi], st["omega"][lo:hi], st["motor_rpm"][lo:hi])
+        g.set_input(0, hi - lo, oracle.ACTUATOR_CMD, cmd[lo:hi])
+        shards.append((g, lo, hi))
+    for tick in range(200):
+        crash = tick == 150
+        o.step(DT)
+        o.handle_collisions(True, crash, 100.0)
+        for r, (g, lo, hi) in enumerate(shards):
+            g.step(DT)
+            g.pack_positions_to(recv[r * n_max:].data_ptr())
+        for g, _, _ in shards:
+            g.synchronize()
+        for r, (g, lo, hi) in enumerate(shards):
+            g.handle_collisions_gathered(recv.data_ptr(), world * n_max, r * n_max, True, crash, 100.0)
+        if tick % 40 == 39 or tick == 150:
+            so = o.get_state()
+            for r, (g, lo, hi) in enumerate(shards):
+                helpers.assert_close(g.get_external_force(), o.get_external_force(lo, hi - lo), 1e-11, f"tick {tick} shard {r} forces")
+                assert np.array_equal(g.has_crashed(), o.has_crashed(lo, hi - lo)), f"tick {tick} shard {r} crash flags"
+                sg = g.get_state()
+                for k in ("x", "v", "R", "omega"):
+                    helpers.assert_close(sg[k], so[k][lo:hi], RTOL_LITERAL, f"tick {tick} shard {r} {k}")
+    assert o.has_crashed().sum() > 0 and (np.abs(o.get_external_force()).sum(axis=1) > 0).sum() > 50
+    for g, _, _ in shards:
+        ticks, searches = g.collision_stats()
+        assert ticks == 200
+        if os.environ.get("MRS_NEIGHBOUR_LISTS", "1") != "0":
+            assert 2 <= searches <= 80, f"{searches} searches in {ticks} gathered ticks"
