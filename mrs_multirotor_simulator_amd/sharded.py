@@ -30,17 +30,23 @@ class GpuEngine:
 
     def __init__(self, swarm, device):
         self.swarm, self.device = swarm, device
+        # the swarm's own HIP stream as a torch stream: the hand-over to and from the collective (which runs on torch's current
+        # stream) is then stream-to-stream ordering through events — no host synchronisation inside a tick
+        self.ext = torch.cuda.ExternalStream(swarm.stream(), device=device)
 
     def step(self, dt):
         self.swarm.step(dt)
 
     def write_records(self, out):  # out: (n_local, 6) float64 slice of the send buffer on self.device
         self.swarm.pack_positions_to(out.data_ptr())
-        self.swarm.synchronize()  # the collective runs on torch's stream
+        torch.cuda.current_stream(self.device).wait_stream(self.ext)  # the collective starts after the pack kernel
 
     def collide(self, records, n_records, my_offset, enabled, crash, rebounce):
-        torch.cuda.current_stream(self.device).synchronize()
+        self.ext.wait_stream(torch.cuda.current_stream(self.device))  # the collision pass starts after the collective
         self.swarm.handle_collisions_gathered(records.data_ptr(), n_records, my_offset, enabled, crash, rebounce)
+        # the next tick's pack overwrites the send buffer and the next collective the receive buffer: both are ordered behind
+        # this pass on the swarm's stream / by the wait above
+        torch.cuda.current_stream(self.device).wait_stream(self.ext)
 
 
 class ShardedSwarm:
