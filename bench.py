@@ -150,13 +150,29 @@ def main():
     coll = args.workload.endswith("collisions")
 
     sharded = None
-    if coll and world > 1:  # BASELINE configs[4]: index shards + ONE all-gather of 48-B records per tick (RCCL over xGMI)
-        from mrs_multirotor_simulator_amd.sharded import GpuEngine, ShardedSwarm
-        dev = torch.device("cuda", local)
-        sharded = ShardedSwarm(n * world, GpuEngine(sw, dev), dev)
+    native_comm = False
+    force_comm = os.environ.get("MRS_NATIVE_RCCL") == "force"  # rehearse the multi-rank code path with a one-rank communicator
+    if coll and (world > 1 or force_comm):  # BASELINE configs[4]: index shards + ONE all-gather of 48-B records per tick (RCCL over xGMI)
+        if os.environ.get("MRS_NATIVE_RCCL", "1") != "0":
+            # the library issues the all-gather itself on the swarm's stream (mrs_swarm_tick_sharded_n): K ticks = one host call
+            from mrs_multirotor_simulator_amd.swarm import rccl_unique_id
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).cuda()
+            if use_dist:
+                dist.broadcast(uid, 0)
+            sw.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()), n * world)
+            native_comm = True
+            sharded = sw
+        else:  # the same exchange driven from Python through torch.distributed (sharded.py)
+            from mrs_multirotor_simulator_amd.sharded import GpuEngine, ShardedSwarm
+            dev = torch.device("cuda", local)
+            sharded = ShardedSwarm(n * world, GpuEngine(sw, dev), dev)
 
     def run(k):
-        if sharded is not None:
+        if native_comm:
+            sw.tick_sharded_n(DT, k, True, False, 100.0)
+        elif sharded is not None:
             sharded.tick_n(DT, k, True, False, 100.0)
         elif coll:
             sw.tick_n(DT, k, True, False, 100.0)
@@ -218,7 +234,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {args.workload} references, dt=1 ms, RK4, ground on"
                        if args.workload == "actuator" else f"{n} x500 UAVs per GPU, {args.workload}, dt=1 ms",
                        "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
-                       "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and world > 1)
+                       "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and (world > 1 or native_comm))
                                        else f"{world} independent shard(s), no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name if not coll
@@ -234,6 +250,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, st, cmd)
         print(json.dumps(out), flush=True)
+    if native_comm:
+        sw.comm_destroy()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -209,6 +209,21 @@ int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst);
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,
                                          int32_t enabled, int32_t crash, double rebounce);
 
+/* The same exchange done by the library itself, for hosts that do not want to drive RCCL: the all-gather is issued on the
+ * swarm's own stream between the step kernel and the collision pass, so a whole run of ticks is one asynchronous call.
+ * RCCL is bound at run time from `librccl_path` (NULL = "librccl.so" from the loader path; a process that already holds a HIP
+ * runtime — PyTorch-ROCm ships its own — must name the librccl.so that belongs to THAT runtime).
+ *   mrs_rccl_unique_id   : rank 0 creates the 128-byte id and hands it to the other ranks by any host channel
+ *   mrs_swarm_comm_init  : collective; shards are the static contiguous index ranges of n_total UAVs over `world` ranks
+ *                          (sizes differ by at most one, larger shards first); this swarm must hold the shard of `rank`
+ *   mrs_swarm_tick_sharded_n : n_ticks of timerMain on every rank — makeStep, then handleCollisions over ALL n_total UAVs
+ *                          (src/multirotor_simulator.cpp:211-217, 295-359); collective, asynchronous
+ *   mrs_swarm_comm_destroy   : collective */
+int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128);
+int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total);
+int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
+int mrs_swarm_comm_destroy(mrs_swarm_t* s);
+
 /* collision-pass statistics of mrs_swarm_handle_collisions / mrs_swarm_tick_n: ticks that ran the pass, and how many of them had to
  * repeat the neighbour search (the others reused the neighbour lists of an earlier tick — same results as the reference's per-tick
  * kd-tree, src/multirotor_simulator.cpp:303-317, which this replaces) */

@@ -11,6 +11,7 @@
 
 #include <map>
 #include <mutex>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -219,6 +220,20 @@ static void angle_axis_z(double angle, double R[9]) {
 // swarm object
 // ------------------------------------------------------------------------------------------------
 
+// RCCL entry points, bound at run time by rccl_load() below
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*)                                             = nullptr;
+  int (*CommInitRank)(void**, int, const void* /* by value, 128 B */, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t)  = nullptr;
+  int (*CommDestroy)(void*)                                              = nullptr;
+  const char* (*GetErrorString)(int)                                     = nullptr;
+};
+struct NcclId { char internal[128]; };
+RcclApi g_rccl;
+}  // namespace
+
 struct mrs_swarm {
   // every C-ABI call on a swarm is serialised (the reference's subscriber callbacks run concurrently with timerMain and are
   // serialised by mutex_uav_system_, src/uav_system_ros.cpp:267,702): recursive because entry points call each other
@@ -231,6 +246,12 @@ struct mrs_swarm {
   hipStream_t stream2 = nullptr;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   bool        split_steps = true;  // tuning: MRS_SPLIT_STREAMS=0
+  // native multi-GPU collision exchange (mrs_swarm_comm_init): RCCL all-gather issued on `stream`
+  void*      rccl_comm = nullptr;
+  int        comm_world = 0, comm_rank = 0;
+  int64_t    comm_n_total = 0, comm_n_max = 0;
+  PosRecord* comm_send = nullptr;
+  PosRecord* comm_recv = nullptr;
   double*   dS = nullptr;
   uint32_t* dF = nullptr;
   TypeParams* dT = nullptr;
@@ -610,6 +631,9 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   (void)hipFree(s->dDiag);
   (void)hipFree(s->dF);
   (void)hipFree(s->dS);
+  if (s->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->rccl_comm);
+  if (s->comm_send) (void)hipFree(s->comm_send);
+  if (s->comm_recv) (void)hipFree(s->comm_recv);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -1000,6 +1024,115 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
   if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
   HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->dRec, s->n, 0, crash, rebounce, /*rec_is_local_scratch=*/1, s->stream));
   return MRS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, bound at run time: the process must use ONE HIP runtime, so the library named by the caller is loaded (PyTorch-ROCm
+// ships its own librccl.so next to its own libamdhip64; a plain C++ host passes NULL for the system one)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+int rccl_load(const char* path) {
+  if (g_rccl.lib) return MRS_OK;
+  void* lib = dlopen(path && *path ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(MRS_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
+  g_rccl.lib = lib;
+  g_rccl.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+  *(void**)&g_rccl.CommInitRank = dlsym(lib, "ncclCommInitRank");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.CommInitRank) {
+    g_rccl = RcclApi();
+    return fail(MRS_ERR_HIP, "the RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+  }
+  return MRS_OK;
+}
+int rccl_check(int rc, const char* what) {
+  if (rc == 0) return MRS_OK;
+  return fail(MRS_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128) {
+  if (!id128) return fail(MRS_ERR_ARG, "null id");
+  int rc = rccl_load(librccl_path);
+  if (rc) return rc;
+  NcclId id;
+  if ((rc = rccl_check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId"))) return rc;
+  memcpy(id128, id.internal, 128);
+  return MRS_OK;
+}
+
+int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total) {
+  MRS_LOCK(s);
+  if (!s || !id128) return fail(MRS_ERR_ARG, "null argument");
+  if (world < 1 || rank < 0 || rank >= world || n_total < s->n) return fail(MRS_ERR_ARG, "bad communicator shape");
+  const int64_t base = n_total / world, rem = n_total % world;
+  const int64_t mine = base + (rank < rem ? 1 : 0);  // static contiguous index shards, sizes differ by at most one
+  if (mine != s->n) return fail(MRS_ERR_ARG, "this swarm does not hold the shard of its rank (n_total / world UAVs, the first n_total % world ranks one more)");
+  HIPCHK(hipSetDevice(s->device));
+  int rc = rccl_load(librccl_path);
+  if (rc) return rc;
+  if (s->rccl_comm) return fail(MRS_ERR_ARG, "communicator already initialised");
+  NcclId id;
+  memcpy(id.internal, id128, 128);
+  typedef int (*init_fn)(void**, int, NcclId, int);
+  if ((rc = rccl_check(((init_fn)g_rccl.CommInitRank)(&s->rccl_comm, world, id, rank), "ncclCommInitRank"))) return rc;
+  s->comm_world   = world;
+  s->comm_rank    = rank;
+  s->comm_n_total = n_total;
+  s->comm_n_max   = (n_total + world - 1) / world;
+  HIPCHK(hipMalloc(&s->comm_send, sizeof(PosRecord) * (size_t)s->comm_n_max));
+  HIPCHK(hipMalloc(&s->comm_recv, sizeof(PosRecord) * (size_t)s->comm_n_max * (size_t)world));
+  HIPCHK(hipMemsetAsync(s->comm_send, 0xFF, sizeof(PosRecord) * (size_t)s->comm_n_max, s->stream));  // NaN padding records never collide
+  return MRS_OK;
+}
+
+int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
+  MRS_LOCK(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!s->rccl_comm) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  int rc = rccl_check(g_rccl.CommDestroy(s->rccl_comm), "ncclCommDestroy");
+  s->rccl_comm = nullptr;
+  if (s->comm_send) (void)hipFree(s->comm_send);
+  if (s->comm_recv) (void)hipFree(s->comm_recv);
+  s->comm_send = s->comm_recv = nullptr;
+  return rc;
+}
+
+// timerMain on every rank of a sharded swarm: step, pack, ONE all-gather of the 48-B records on the swarm's own stream, collision
+// pass against the gathered records — no host synchronisation and no other stream inside the loop
+int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
+  MRS_LOCK(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (!s->rccl_comm) return fail(MRS_ERR_ARG, "mrs_swarm_comm_init has not been called");
+  if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
+  if (n_ticks == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, dt);
+  if (rc) return rc;
+  if ((rc = begin_profile(s))) return rc;
+  const int64_t n_rec = s->comm_n_max * s->comm_world;
+  for (int k = 0; k < n_ticks; k++) {
+    if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
+    if (!(crash || enabled)) continue;  // src/multirotor_simulator.cpp:299-301
+    if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
+    if ((rc = rccl_check(g_rccl.AllGather(s->comm_send, s->comm_recv, (size_t)s->comm_n_max * 6, /*ncclFloat64*/ 8, s->rccl_comm, s->stream),
+                         "ncclAllGather")))
+      return rc;
+    if (s->n == 0) continue;
+    s->fext_active = true;
+    s->collision_ticks++;
+    s->nbr_dirty = true;
+    if (s->use_lists)
+      HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, crash, rebounce, s->stream));
+    else
+      HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, crash, rebounce, 0, s->stream));
+  }
+  return finish_profile(s);
 }
 
 int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {

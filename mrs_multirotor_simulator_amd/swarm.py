@@ -76,6 +76,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
+    "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -99,6 +100,26 @@ def _preload_hip_runtime():
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
             except OSError:
                 return
+
+
+def default_librccl_path():
+    """The librccl.so that belongs to the HIP runtime this process uses: torch's bundled copy when torch is installed (see
+    _preload_hip_runtime), otherwise None = the system one from the loader path."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    return path if os.path.exists(path) else None
+
+
+def rccl_unique_id(librccl_path=None):
+    """128-byte communicator id, created on rank 0 and handed to the other ranks over any host channel."""
+    load_library()
+    path = default_librccl_path() if librccl_path is None else librccl_path
+    buf = (C.c_uint8 * 128)()
+    _check(_lib.mrs_rccl_unique_id(path.encode() if path else None, C.cast(buf, C.c_void_p)))
+    return bytes(buf)
 
 
 def load_library():
@@ -154,6 +175,10 @@ def load_library():
         "mrs_swarm_pack_positions": [vp, C.POINTER(vp), C.POINTER(C.c_int64)],
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
+        "mrs_rccl_unique_id": [C.c_char_p, vp],
+        "mrs_swarm_comm_init": [vp, C.c_char_p, i32, i32, vp, C.c_int64],
+        "mrs_swarm_tick_sharded_n": [vp, f64, i32, i32, i32, f64],
+        "mrs_swarm_comm_destroy": [vp],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -328,6 +353,18 @@ class Swarm:
     def handle_collisions_gathered(self, dev_ptr, n_total, my_offset, enabled, crash, rebounce):
         _check(_lib.mrs_swarm_handle_collisions_gathered(self._h, C.c_void_p(dev_ptr), n_total, my_offset, int(enabled),
                                                          int(crash), float(rebounce)))
+
+    # the exchange driven by the library itself (RCCL bound at run time, all-gather on the swarm's stream)
+    def comm_init(self, world, rank, unique_id, n_total, librccl_path=None):
+        path = default_librccl_path() if librccl_path is None else librccl_path
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(_lib.mrs_swarm_comm_init(self._h, path.encode() if path else None, world, rank, C.cast(buf, C.c_void_p), n_total))
+
+    def tick_sharded_n(self, dt, n_ticks, enabled, crash, rebounce):
+        _check(_lib.mrs_swarm_tick_sharded_n(self._h, dt, n_ticks, int(enabled), int(crash), float(rebounce)))
+
+    def comm_destroy(self):
+        _check(_lib.mrs_swarm_comm_destroy(self._h))
 
     # -- state --
     def get_state(self, first=0, count=None):

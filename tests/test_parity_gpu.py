@@ -891,3 +891,59 @@ def test_gathered_collisions_reuse_neighbour_lists_over_many_ticks(M, oracle):
         assert ticks == 200
         if os.environ.get("MRS_NEIGHBOUR_LISTS", "1") != "0":
             assert 2 <= searches <= 80, f"{searches} searches in {ticks} gathered ticks"
+
+
+def test_library_driven_sharded_tick_with_a_one_rank_communicator(M, oracle):
+    """mrs_swarm_tick_sharded_n: the library issues the all-gather itself (RCCL bound at run time, on the swarm's stream).  A
+    one-rank communicator exercises the whole path on the single-GPU box — unique id, communicator, NaN-padded send buffer,
+    all-gather, gathered collision pass with neighbour lists — and must reproduce mrs_swarm_tick_n on a twin swarm and the oracle.
+    A shard that is not the one of its rank is refused."""
+    from mrs_multirotor_simulator_amd import swarm as S
+    rng = np.random.default_rng(77)
+    n = 2500
+    side = (64.0 * n) ** (1.0 / 3.0)
+    pos = rng.uniform(0, side, (n, 3)) + [0, 0, 30]
+    pos[:150] = pos[150:300] + rng.normal(0, 0.3, (150, 3))
+    st = helpers.random_state(rng, n, 4, tilted=True)
+    st["x"] = pos
+    st["v"] = rng.normal(0, 5.0, (n, 3))
+    cmd = rng.uniform(0.4, 0.55, (n, 4))
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    o = oracle.OracleSwarm(n)
+    o.construct(0, n, po, pos, np.zeros(n))
+    o.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, n, oracle.ACTUATOR_CMD, cmd)
+    twins = []
+    for _ in range(2):
+        g = M.Swarm(n)
+        g.construct(0, n, helpers.to_product_params(M, po), pos, np.zeros(n))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        g.set_input(0, n, oracle.ACTUATOR_CMD, cmd)
+        twins.append(g)
+    a, b = twins
+    uid = S.rccl_unique_id()
+    assert len(uid) == 128
+    with pytest.raises(M.MrsError):
+        a.tick_sharded_n(DT, 1, True, False, 100.0)  # no communicator yet
+    with pytest.raises(M.MrsError):
+        a.comm_init(1, 0, uid, n + 5)  # n_total does not match the shard of rank 0
+    a.comm_init(1, 0, uid, n)
+    for block, crash in ((60, False), (1, True), (59, False)):
+        a.tick_sharded_n(DT, block, True, crash, 100.0)
+        b.tick_n(DT, block, True, crash, 100.0)
+        for _ in range(block):
+            o.step(DT)
+            o.handle_collisions(True, crash, 100.0)
+        sa, sb, so = a.get_state(), b.get_state(), o.get_state()
+        for k in ("x", "v", "R", "omega", "motor_rpm"):
+            helpers.assert_close(sa[k], sb[k], RTOL_LITERAL, "twin " + k)
+            helpers.assert_close(sa[k], so[k], RTOL_LITERAL, k)
+        helpers.assert_close(a.get_external_force(), b.get_external_force(), 1e-11, "twin forces")
+        helpers.assert_close(a.get_external_force(), o.get_external_force(), 1e-11, "forces")
+        assert np.array_equal(a.has_crashed(), o.has_crashed())
+    assert o.has_crashed().sum() > 0
+    assert a.collision_stats()[0] == 120
+    a.comm_destroy()
+    a.comm_destroy()  # idempotent
+    with pytest.raises(M.MrsError):
+        a.tick_sharded_n(DT, 1, True, False, 100.0)
