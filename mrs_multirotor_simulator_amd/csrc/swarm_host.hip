@@ -1033,10 +1033,11 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
 namespace {
 
 int rccl_load(const char* path) {
+  static std::mutex load_mtx;  // swarms of different host threads may initialise their communicators concurrently
+  std::lock_guard<std::mutex> lk(load_mtx);
   if (g_rccl.lib) return MRS_OK;
   void* lib = dlopen(path && *path ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return fail(MRS_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
-  g_rccl.lib = lib;
   g_rccl.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
@@ -1044,8 +1045,10 @@ int rccl_load(const char* path) {
   *(void**)&g_rccl.CommInitRank = dlsym(lib, "ncclCommInitRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.CommInitRank) {
     g_rccl = RcclApi();
+    dlclose(lib);
     return fail(MRS_ERR_HIP, "the RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
   }
+  g_rccl.lib = lib;  // last: the unlocked readers (the communicator calls) only run after a successful load
   return MRS_OK;
 }
 int rccl_check(int rc, const char* what) {
