@@ -16,6 +16,7 @@
 
 #include <memory>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "multirotor_model.hpp"
@@ -232,6 +233,21 @@ public:
   void tick(double dt, int n_ticks, bool enabled, bool crash, double rebounce) {  // timerMain order, :211-217
     mrs_throw_on_error(mrs_swarm_tick_n(s_, dt, n_ticks, enabled, crash, rebounce));
   }
+  // ---- one shard per GPU/process: this swarm holds the UAVs of `rank` out of n_total, collisions act across all shards ----
+  // rank 0 creates the id and hands it to the others (any host channel); librccl_path = nullptr loads the system librccl.so
+  static std::array<uint8_t, 128> commUniqueId(const char* librccl_path = nullptr) {
+    std::array<uint8_t, 128> id{};
+    mrs_throw_on_error(mrs_rccl_unique_id(librccl_path, id.data()));
+    return id;
+  }
+  void commInit(int world, int rank, const std::array<uint8_t, 128>& id, int64_t n_total, const char* librccl_path = nullptr) {
+    mrs_throw_on_error(mrs_swarm_comm_init(s_, librccl_path, world, rank, id.data(), n_total));
+  }
+  // timerMain x n_ticks on every rank: makeStep, all-gather of the 48-B records on the swarm's stream, handleCollisions over all UAVs
+  void tickSharded(double dt, int n_ticks, bool enabled, bool crash, double rebounce) {
+    mrs_throw_on_error(mrs_swarm_tick_sharded_n(s_, dt, n_ticks, enabled, crash, rebounce));
+  }
+  void commDestroy() { mrs_throw_on_error(mrs_swarm_comm_destroy(s_)); }
   void synchronize() { mrs_throw_on_error(mrs_swarm_synchronize(s_)); }
   // collision ticks so far, and how many of them had to repeat the neighbour search
   std::pair<int64_t, int64_t> collisionStats() {

@@ -101,6 +101,20 @@ def test_simulator_over_the_swarm_on_gpu(mrs):
         assert f"ok {tag}" in out.stdout, out.stdout
 
 
+def test_sharded_tick_host_compiles(mrs):
+    assert os.path.exists(_build_cpp(mrs, "sharded_tick_test"))
+
+
+@pytest.mark.gpu
+def test_library_driven_sharded_tick_from_a_cpp_host(mrs):
+    """mrs_swarm_comm_init / tick_sharded_n in a process without PyTorch: RCCL from the system loader path, one-rank communicator,
+    same results as the local ticks, crash mode, destroy."""
+    out = subprocess.run([_build_cpp(mrs, "sharded_tick_test")], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for tag in ("communicator", "sharded_ticks_equal_local_ticks", "crash_and_destroy"):
+        assert f"ok {tag}" in out.stdout, out.stdout
+
+
 def _build_example(mrs):
     from mrs_multirotor_simulator_amd import swarm
     exe = os.path.join(ROOT, "tests", "cpp", "standalone_swarm")
