@@ -8,7 +8,8 @@
  *
  * Parity status: dynamics/cascade "parity unpinned" (no reference tests/vectors
  * exist; reference headers need Eigen3+Boost, absent here); collision neighbour
- * set pinned against the reference's nanoflann (oracle/_ref).
+ * set pinned against the reference's nanoflann (oracle/_ref).  Cross-checked at 1e-9
+ * against a second, independently written restatement (tests/independent_model.py).
  */
 #include "uav_oracle.h"
 
