@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long differential run: a dense, moving swarm with elastic collisions, position commands that change, occasional crashes and
 holds — product (tick_n) vs oracle (step + handle_collisions per tick), compared every `chunk` ticks.
-usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast] [m^3 per UAV]"""
+usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast] [m^3 per UAV] [local|sharded]
+`sharded` drives the ticks through mrs_swarm_tick_sharded_n with a one-rank RCCL communicator (the multi-GPU code path)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,11 +18,15 @@ rtol = 1e-6 if fast else 1e-10
 DT, chunk = 0.001, 250
 rng = np.random.default_rng(2026)
 vol = float(sys.argv[4]) if len(sys.argv) > 4 else 30.0  # m^3 per UAV (30: plenty of contacts)
+sharded = len(sys.argv) > 5 and sys.argv[5] == "sharded"
 side = (vol * n) ** (1.0 / 3.0)
 p = Pair(M, n, arith=M.ARITH_FAST if fast else M.ARITH_LITERAL)
 pos = rng.uniform(0, side, (n, 3)) + [0, 0, 1.0]
 p.construct(0, n, "x500", pos=pos, heading=rng.uniform(-3, 3, n), ground_enabled=True, ground_z=0.0)
 p.both("set_input", 0, n, O.POSITION_CMD, np.concatenate([pos + rng.uniform(-6, 6, (n, 3)), rng.uniform(-3, 3, (n, 1))], axis=1))
+if sharded:
+    from mrs_multirotor_simulator_amd.swarm import rccl_unique_id
+    p.g.comm_init(1, 0, rccl_unique_id(), n)
 t0 = time.time()
 worst = 0.0
 for c in range(ticks // chunk):
@@ -34,11 +39,11 @@ for c in range(ticks // chunk):
     for _ in range(chunk):
         p.o.step_n(DT, 1, 16)
         p.o.handle_collisions(True, False, 100.0)
-    p.g.tick_n(DT, chunk, True, False, 100.0)
+    (p.g.tick_sharded_n if sharded else p.g.tick_n)(DT, chunk, True, False, 100.0)
     e = p.compare(rtol, f"after {(c + 1) * chunk} ticks")
     helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), max(rtol, 1e-11), "forces")
     assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
     worst = max(worst, e)
     touched = int((np.abs(p.o.get_external_force()).sum(axis=1) > 0).sum())
     print(f"tick {(c + 1) * chunk:6d}: max rel err {e:.2e}, {touched} UAVs in contact, collision stats {p.g.collision_stats()}, {time.time() - t0:.0f} s", flush=True)
-print("SOAK OK", n, "UAVs", ticks, "ticks", "fast" if fast else "literal", "worst", worst)
+print("SOAK OK", n, "UAVs", ticks, "ticks", "fast" if fast else "literal", "sharded" if sharded else "local", "worst", worst)
