@@ -703,11 +703,13 @@ print("RESULT" + json.dumps(out))
                 helpers.assert_close(a, b, RTOL_FAST, f"fast: {k}")
 
 
-def test_state_array_beyond_2_GiB_still_addresses_every_column(M, oracle):
-    """3.2 M UAVs = 2.2 GiB of state: the 32-bit buffer offsets of the step kernel run past 2^31.  Replica property (all copies
-    of a 4096-UAV swarm stay bit-identical, the last column of the last copy included) + the first copy against the oracle."""
+@pytest.mark.parametrize("n", [3_200_000, 6_500_000])
+def test_state_array_beyond_2_GiB_still_addresses_every_column(M, oracle, n):
+    """3.2 M UAVs = 2.2 GiB of state: the 32-bit buffer offsets of the step kernel run past 2^31.  6.5 M UAVs = 4.5 GiB: past the
+    reach of a buffer resource, the launcher switches to the pointer-addressed kernels with 64-bit column offsets.  Replica property
+    (all copies of a 4096-UAV swarm stay bit-identical, the last column of the last copy included) + the first copy against the oracle."""
     rng = np.random.default_rng(56)
-    m, n = 4096, 3_200_000
+    m = 4096
     reps = -(-n // m)
     st = random_state(rng, m, 4)
     cmd = rng.uniform(0.35, 0.6, (m, 4))
@@ -732,7 +734,7 @@ def test_state_array_beyond_2_GiB_still_addresses_every_column(M, oracle):
     o.step_n(DT, 50)
     ref = o.get_state()
     for k in ("x", "v", "R", "omega", "motor_rpm"):
-        helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"3.2M swarm, first copy vs oracle: {k}")
+        helpers.assert_close(out[k][:m], ref[k], RTOL_NORTH_STAR, f"{n} UAVs, first copy vs oracle: {k}")
 
 
 def test_fast_kernel_nan_lane_does_not_disturb_its_wave(M, oracle):
