@@ -215,11 +215,13 @@ def main():
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args, n)
-        # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD
+        # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
+        # non-temporal accesses for model-only steps of small swarms
         npad = (n + 63) // 64 * 64
         kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
         if 86 * npad * 8 < 2 ** 32:
-            kernel_name += "_buf" + ("_w3" if (args.substeps == 1 and npad // 64 > 2048 and args.arith == "fast") else "")
+            fast1 = args.substeps == 1 and args.arith == "fast"
+            kernel_name += "_buf" + ("_w3" if (fast1 and npad // 64 > 2048) else "_nt" if (fast1 and args.workload == "actuator") else "")
         kernel_name += "_" + args.arith
         # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1

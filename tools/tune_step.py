@@ -22,6 +22,12 @@ VARIANTS = {
     "memclause": "-mllvm -amdgpu-sched-strategy=max-memory-clause",
     "O2": "-O2",
     "nolicm": "-mllvm -disable-licm-promotion",
+    "st_nt": "-DMRS_ST_AUX=2",
+    "st_sc1": "-DMRS_ST_AUX=16",
+    "st_sc01": "-DMRS_ST_AUX=17",
+    "st_sc01nt": "-DMRS_ST_AUX=19",
+    "ld_nt": "-DMRS_LD_AUX=2",
+    "ldst_nt": "-DMRS_LD_AUX=2 -DMRS_ST_AUX=2",
 }
 
 
@@ -40,6 +46,9 @@ def main():
     out_dir = "/tmp/mrs_variants"
     os.makedirs(out_dir, exist_ok=True)
     for name in args.variants.split(","):
+        if name.startswith("aux_"):  # aux_<load bits>_<store bits>: cache policy of the state accesses
+            _, la, sa = name.split("_")
+            VARIANTS[name] = f"-DMRS_LD_AUX={la} -DMRS_ST_AUX={sa}"
         flags = (VARIANTS[name] + " " + args.extra).split()
         objs = []
         for v, c in (("literal", "off"), ("fast", "fast")):
