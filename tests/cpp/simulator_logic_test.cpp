@@ -128,7 +128,7 @@ int main() {
     cfg.realtime_factor = 2.0;
     Sim sim(sw, 1, cfg);
     sim.spinFor(0.25);
-    CHECK(sim.ticks() > 60 && sim.ticks() <= 101);
+    CHECK(sim.ticks() >= 10 && sim.ticks() <= 101);  // never more than rate x RTF x time; a loaded host may lose ticks (no catch-up bursts)
     const int64_t before = sim.ticks();
     sim.reconfigure(2.0, true, true, true, 100.0);
     sim.spinFor(0.05);
