@@ -950,7 +950,8 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   if (rc) return rc;
   if ((rc = begin_profile(s))) return rc;
   // enough launches to overlap, enough blocks for two useful halves, and no per-launch events to keep in order
-  const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= 1024 && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
+  static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
+  const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
   if (split && (rc = fork_streams(s))) return rc;
   int left = n_steps;
   while (left > 0) {
