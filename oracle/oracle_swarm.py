@@ -63,7 +63,8 @@ def build(force=False):
     if force or stale:
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref = os.path.join(HERE, "_ref", "libref_nanoflann.so")
-    if os.path.exists("/root/reference/include/nanoflann.hpp") and (force or not os.path.exists(ref)):
+    ref_pid = os.path.join(HERE, "_ref", "libref_pid.so")
+    if os.path.exists("/root/reference/include/nanoflann.hpp") and (force or not os.path.exists(ref) or not os.path.exists(ref_pid)):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -294,6 +295,29 @@ def ref_lib():
         _ref.ref_nf_build_and_count.restype = C.c_int64
         _ref.ref_nf_build_and_count.argtypes = [C.POINTER(C.c_double), C.c_int32, C.c_double, C.c_int32]
     return _ref
+
+
+_ref_pid = None
+
+
+def ref_pid_lib():
+    """The REFERENCE's own PIDController (controllers/pid.hpp compiled where it lies into oracle/_ref/libref_pid.so), or None."""
+    global _ref_pid
+    if _ref_pid is None:
+        build()
+        path = os.path.join(HERE, "_ref", "libref_pid.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.ref_pid_create.restype = C.c_void_p
+        L.ref_pid_destroy.argtypes = [C.c_void_p]
+        L.ref_pid_reset.argtypes = [C.c_void_p]
+        L.ref_pid_set_params.argtypes = [C.c_void_p] + [C.c_double] * 5
+        L.ref_pid_set_saturation.argtypes = [C.c_void_p, C.c_double]
+        L.ref_pid_update.restype = C.c_double
+        L.ref_pid_update.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _ref_pid = L
+    return _ref_pid
 
 
 def ref_radius_neighbours(pts, radius=3.0, leaf_max_size=10):

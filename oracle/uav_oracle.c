@@ -7,8 +7,10 @@
  * Build with -O2 -ffp-contract=off (never -ffast-math): NaN semantics are load-bearing.
  *
  * Parity status: dynamics/cascade "parity unpinned" (no reference tests/vectors
- * exist; reference headers need Eigen3+Boost, absent here); collision neighbour
- * set pinned against the reference's nanoflann (oracle/_ref).  Cross-checked at 1e-9
+ * exist; reference headers need Eigen3+Boost, absent here), EXCEPT the PID
+ * (pid.hpp compiles alone: pinned bit for bit against the reference's own class,
+ * oracle/_ref/libref_pid.so + tests/golden/pid_reference_vectors.npz); collision
+ * neighbour set pinned against the reference's nanoflann (oracle/_ref).  Cross-checked at 1e-9
  * against a second, independently written restatement (tests/independent_model.py).
  */
 #include "uav_oracle.h"

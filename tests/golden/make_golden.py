@@ -5,6 +5,10 @@
   KDTreeVectorOfVectorsAdaptor.h compiled unmodified (oracle/Makefile -> oracle/_ref) and queried exactly like
   src/multirotor_simulator.cpp:309-328 (3 dims, leaf_max_size 10, RadiusResultSet(3.0)) on seeded point clouds.
   Inputs (points) and outputs (CSR neighbour lists with squared distances) are stored.
+* pid_reference_vectors.npz — OUTPUT OF THE REFERENCE'S OWN CODE: PIDController of
+  include/mrs_multirotor_simulator/uav_system/controllers/pid.hpp (the one controller header that needs neither Eigen nor Boost),
+  compiled unmodified into oracle/_ref/libref_pid.so and driven with seeded (error, dt) sequences; parameters, stimulus and the
+  outputs of update() are stored.
 * oracle_trajectories.npz — regression vectors of the CPU oracle (NOT reference outputs: the reference's dynamics cannot be
   built here) for BASELINE config 1 and a 64-UAV mixed-mode swarm; they freeze the oracle so that a later
   edit of oracle/uav_oracle.c cannot silently move the parity target.
@@ -152,9 +156,71 @@ def all_modes():
                         rpm0=st0["motor_rpm"], x=st["x"], v=st["v"], R=st["R"], w=st["omega"], rpm=st["motor_rpm"], imu=s.get_imu(), pid=s.get_pid())
 
 
+def pid_sequences(seed=77, n_seq=96, n_steps=160):
+    """Stimulus of the PID pinning vectors: per sequence one parameter set (the four gain sets of the cascade and random ones;
+    saturation and anti-windup positive, zero and negative) and a run of (error, dt) pairs that walks through the derivative
+    kick, both saturation sides (with exact hits of the bounds), the anti-windup threshold, sign changes, dt changes, a NaN and an
+    infinite error, and a setSaturation / reset in the middle."""
+    rng = np.random.default_rng(seed)
+    cascade = [(2.0, 0.15, 0.2, 6.0, 1.0), (2.0, 0.05, 0.01, 4.0, 1.0), (6.0, 0.05, 0.01, 10.0, 0.1), (6.0, 0.05, 0.01, 1.0, 0.1),
+               (4.0 * 0.0329, 0.04 * 0.0329, 0.0, -1.0, 1.0)]
+    params = np.zeros((n_seq, 5))
+    err = np.zeros((n_seq, n_steps))
+    dt = np.zeros((n_seq, n_steps))
+    event = np.zeros((n_seq, n_steps))  # 0 none, 1 reset before this update, 2 setSaturation(new_sat) before this update
+    new_sat = np.zeros((n_seq, n_steps))
+    for q in range(n_seq):
+        if q < 3 * len(cascade):
+            params[q] = cascade[q % len(cascade)]
+        else:
+            params[q] = [rng.uniform(0, 8), rng.uniform(0, 0.3), rng.uniform(0, 0.5), rng.choice([-1.0, 0.0, 0.5, 2.0, 6.0]),
+                         rng.choice([-1.0, 0.0, 0.1, 1.0, 3.0])]
+        scale = 10.0 ** rng.uniform(-3, 1.5)
+        e = np.cumsum(rng.normal(0, 0.2, n_steps)) * scale + rng.normal(0, 0.05, n_steps) * scale
+        e[rng.integers(0, n_steps, 6)] *= -1.0
+        kp, sat = params[q, 0], params[q, 3]
+        if kp > 0 and sat > 0:  # exact hits of the bounds through the proportional term alone would need kd = ki = 0; near hits do
+            e[rng.integers(1, n_steps)] = sat / kp
+            e[rng.integers(1, n_steps)] = -sat / kp
+        err[q] = e
+        dt[q] = rng.choice([0.001, 0.01, 0.004, 1.0 / 3.0 * 0.01], n_steps) if q % 3 == 0 else rng.choice([0.001, 0.01])
+        if q % 8 == 5:
+            err[q, n_steps // 2] = np.nan
+        if q % 8 == 6:
+            err[q, n_steps // 2] = np.inf
+        if q % 4 == 1:
+            event[q, n_steps // 3] = 1
+        if q % 4 == 2:
+            event[q, 2 * n_steps // 3] = 2
+            new_sat[q, 2 * n_steps // 3] = rng.choice([0.5, 3.0, -1.0])
+    return params, err, dt, event, new_sat
+
+
+def pid_reference():
+    """Golden vectors from the REFERENCE's own PIDController (controllers/pid.hpp compiled where it lies into
+    oracle/_ref/libref_pid.so): the outputs of update() for the sequences above.  tests/test_pid_ref.py holds the oracle to them."""
+    L = O.ref_pid_lib()
+    assert L is not None, "oracle/_ref/libref_pid.so must be built from /root/reference"
+    params, err, dt, event, new_sat = pid_sequences()
+    out = np.zeros_like(err)
+    for q in range(len(params)):
+        h = L.ref_pid_create()
+        L.ref_pid_set_params(h, *params[q])
+        for k in range(err.shape[1]):
+            if event[q, k] == 1:
+                L.ref_pid_reset(h)
+            elif event[q, k] == 2:
+                L.ref_pid_set_saturation(h, new_sat[q, k])
+            out[q, k] = L.ref_pid_update(h, err[q, k], dt[q, k])
+        L.ref_pid_destroy(h)
+    np.savez_compressed(os.path.join(HERE, "pid_reference_vectors.npz"), params=params, err=err, dt=dt, event=event, new_sat=new_sat, out=out)
+    print("pid_reference_vectors.npz:", out.shape, "outputs,", int(np.isnan(out).sum()), "NaN")
+
+
 if __name__ == "__main__":
     nanoflann_sets()
     oracle_trajectories()
     all_modes()
+    pid_reference()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
