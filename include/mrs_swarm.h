@@ -229,6 +229,13 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s);
  * kd-tree, src/multirotor_simulator.cpp:303-317, which this replaces) */
 int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds);
 
+/* test hook: runs the cascade kernels' own PID device function (PIDController::update, controllers/pid.hpp:67-96) over
+ * caller-given sequences on the GPU, one lane per sequence — row-major [n_seq][n_steps] arrays; params = n_seq x
+ * {kp, kd, ki, saturation, antiwindup}; event 1 = reset() before the update, 2 = setSaturation(new_sat) before it.
+ * tests/test_parity_gpu.py feeds it the golden vectors recorded from the reference's own class. */
+int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int32_t n_steps, const double* params, const double* err,
+                            const double* dt, const double* event, const double* new_sat, double* out);
+
 /* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
  * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
  * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */

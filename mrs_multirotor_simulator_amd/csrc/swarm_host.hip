@@ -24,6 +24,8 @@
 
 extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int substeps, int cascade, int blk0, int nblk, int with_mixed, hipStream_t st);
 extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, int cascade, int blk0, int nblk, int with_mixed, hipStream_t st);
+extern "C" hipError_t mrs_launch_pid_probe_literal(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
+extern "C" hipError_t mrs_launch_pid_probe_fast(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
 // collide.hip
 extern "C" hipError_t mrs_launch_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hipStream_t st);
@@ -1390,6 +1392,31 @@ int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_r
 }
 
 // debugging aid for tools/ (deliberately not declared in include/mrs_swarm.h)
+// test hook: the kernels' PID device function over caller-given sequences (see mrs_pid_probe in step_device.inc)
+int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int32_t n_steps, const double* params, const double* err,
+                            const double* dt, const double* event, const double* new_sat, double* out) {
+  if (n_seq < 0 || n_steps < 0 || !params || !err || !dt || !event || !new_sat || !out) return fail(MRS_ERR_ARG, "bad pid probe arguments");
+  if (arith != MRS_ARITH_LITERAL && arith != MRS_ARITH_FAST) return fail(MRS_ERR_ARG, "unknown arithmetic flavour");
+  if (n_seq == 0 || n_steps == 0) return MRS_OK;
+  if (device_id >= 0) HIPCHK(hipSetDevice(device_id));
+  const size_t cells = (size_t)n_seq * (size_t)n_steps;
+  double*      d     = nullptr;  // params | err | dt | event | new_sat | out
+  HIPCHK(hipMalloc(&d, sizeof(double) * ((size_t)n_seq * 5 + cells * 5)));
+  double *dp = d, *de = dp + (size_t)n_seq * 5, *dd = de + cells, *dv = dd + cells, *ds = dv + cells, *dout = ds + cells;
+  hipError_t e = hipMemcpy(dp, params, sizeof(double) * (size_t)n_seq * 5, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(de, err, sizeof(double) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dd, dt, sizeof(double) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, event, sizeof(double) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ds, new_sat, sizeof(double) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = arith == MRS_ARITH_FAST ? mrs_launch_pid_probe_fast(dp, de, dd, dv, ds, dout, n_seq, n_steps, nullptr)
+                                : mrs_launch_pid_probe_literal(dp, de, dd, dv, ds, dout, n_seq, n_steps, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("pid probe: ") + hipGetErrorString(e));
+  return MRS_OK;
+}
+
 int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8) {
   MRS_LOCK(s);
   if (!s || !out8) return fail(MRS_ERR_ARG, "null argument");

@@ -949,3 +949,23 @@ def test_library_driven_sharded_tick_with_a_one_rank_communicator(M, oracle):
     a.comm_destroy()  # idempotent
     with pytest.raises(M.MrsError):
         a.tick_sharded_n(DT, 1, True, False, 100.0)
+
+
+def test_device_pid_reproduces_the_reference_pid_vectors(M):
+    """The cascade kernels' PID device function against the golden vectors recorded from the REFERENCE's own PIDController
+    (tests/golden/pid_reference_vectors.npz, made by make_golden.py:pid_reference from controllers/pid.hpp compiled where it lies).
+    LITERAL: bit for bit, NaN pattern included.  FAST multiplies by 1/dt instead of dividing and may contract a*b+c: within 1e-12
+    of the output scale per update while the loop state stays finite."""
+    from mrs_multirotor_simulator_amd import swarm as S
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pid_reference_vectors.npz"))
+    lit = S.debug_pid_sequences(M.ARITH_LITERAL, g["params"], g["err"], g["dt"], g["event"], g["new_sat"])
+    exp = g["out"]
+    same = (lit.view(np.uint64) == exp.view(np.uint64)) | (np.isnan(lit) & np.isnan(exp))
+    assert same.all(), f"LITERAL: {int((~same).sum())} of {same.size} updates differ, first at {np.argwhere(~same)[0]}"
+    fast = S.debug_pid_sequences(M.ARITH_FAST, g["params"], g["err"], g["dt"], g["event"], g["new_sat"])
+    assert np.array_equal(np.isnan(fast), np.isnan(exp))
+    inf = np.isinf(exp)
+    assert np.array_equal(fast[inf], exp[inf])  # an infinite error without saturation: the same infinity
+    ok = np.isfinite(exp)
+    scale = np.maximum(1.0, np.max(np.where(ok, np.abs(exp), 0.0), axis=1, keepdims=True))
+    assert np.max(np.abs(fast[ok] - exp[ok]) / np.broadcast_to(scale, exp.shape)[ok]) < 1e-12
