@@ -120,6 +120,13 @@ public:
     return st;
   }
 
+  // UavSystemRos::getPose (include/mrs_multirotor_simulator/uav_system_ros.h:48, src/uav_system_ros.cpp:289-292): the position
+  Eigen::Vector3d getPose(void) {
+    double x[3];
+    mrs_throw_on_error(mrs_swarm_get_state(s_, i_, 1, x, nullptr, nullptr, nullptr, nullptr, nullptr));
+    return Eigen::Vector3d(x[0], x[1], x[2]);
+  }
+
   MultirotorModel::ModelParams getParams(void) {  // :395
     mrs_model_params_t c;
     mrs_throw_on_error(mrs_swarm_get_params(s_, i_, &c));

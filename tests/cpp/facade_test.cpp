@@ -51,6 +51,11 @@ int main() {
   std::printf("ALLOC %d %d %.17g %.17g\n", (int)alloc.rows(), (int)alloc.cols(), alloc(0, 0), alloc(3, 2));
   uav_system.crash();
   std::printf("CRASHED %d mass %.17g\n", (int)uav_system.hasCrashed(), uav_system.getParams().mass);
+  {  // UavSystemRos::getPose: the position of getState()
+    const Eigen::Vector3d pose = uav_system.getPose();
+    const auto            st   = uav_system.getState();
+    std::printf("POSE %d\n", (int)(pose(0) == st.x(0) && pose(1) == st.x(1) && pose(2) == st.x(2)));
+  }
 
   // --- a swarm: the simulator loop with one launch per tick ---
   const int n = 400;

@@ -61,6 +61,7 @@ def test_facade_matches_oracle(mrs, oracle):
     check("STEP1100", s, rtol=helpers.RTOL_NORTH_STAR)
     assert rows["ALLOC"][:2] == ["4", "4"] and abs(float(rows["ALLOC"][2]) + np.sqrt(0.5)) < 1e-12 and float(rows["ALLOC"][3]) == 1.0
     assert rows["CRASHED"][0] == "1" and float(rows["CRASHED"][2]) == 2.0
+    assert rows["POSE"][0] == "1"
 
     n = 400
     sw = O.OracleSwarm(n)
