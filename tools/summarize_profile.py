@@ -3,6 +3,32 @@
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
 res = {}
+def derived(pmc):
+    """Figures derived from the per-dispatch averages (SURVEY 8d asks for the VALU share next to the bandwidth)."""
+    g = pmc.get
+    lines = []
+    if g("SQ_WAVES") and g("SQ_INSTS_VALU"):
+        lines.append(f"- vector instructions per wave: {g('SQ_INSTS_VALU') / g('SQ_WAVES'):.0f}")
+    if g("SQ_WAVE_CYCLES"):
+        wc = g("SQ_WAVE_CYCLES")
+        if g("SQ_ACTIVE_INST_VALU"):
+            lines.append(f"- share of a wave's lifetime spent issuing vector ALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES): {g('SQ_ACTIVE_INST_VALU') / wc:.2f}")
+        if g("SQ_WAIT_ANY"):
+            lines.append(f"- share spent waiting on anything, mostly memory (SQ_WAIT_ANY / SQ_WAVE_CYCLES): {g('SQ_WAIT_ANY') / wc:.2f}")
+        if g("SQ_WAIT_INST_ANY"):
+            lines.append(f"- share spent waiting for an instruction to issue (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES): {g('SQ_WAIT_INST_ANY') / wc:.2f}")
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum"):
+        lines.append(f"- L2 hit rate: {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.2f}")
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        lines.append(f"- bytes beyond L2 per dispatch (2 x FETCH_SIZE + WRITE_SIZE, x1024): {(2 * g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / 1e6:.2f} MB")
+    return lines
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--derive":  # print the derived section of an existing summary.json
+    print("\n## Derived\n")
+    print("\n".join(derived(json.load(open(sys.argv[2])).get("pmc", {}))))
+    sys.exit(0)
+
 def find(d, pat):
     f = glob.glob(os.path.join(out, d, "**", pat), recursive=True)
     return f[0] if f else None
@@ -31,6 +57,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for k, v in c.items():
             print(f"- {k}: {v:.6g}  (n={n[k]})")
 res["pmc"] = allc
+print("\n## Derived\n")
+print("\n".join(derived(allc)))
 print("\n## FETCH_SIZE / WRITE_SIZE calibration (tools/mem_floor.hip k_soa: 33 reads + 28 writes of 8 B per UAV, field-major SoA)\n")
 cal = {}
 for tag, ctr, nbytes in (("cal_fetch", "FETCH_SIZE", 33 * 8 + 4), ("cal_write", "WRITE_SIZE", 28 * 8)):
