@@ -88,7 +88,10 @@ def _worker(rank, world, port, n_total, result_dir):
 def test_sharded_ticks_match_single_process(tmp_path, oracle, n_total):
     import helpers
     world = 2
-    port = 29500 + (os.getpid() % 2000) + n_total % 7
+    import socket
+    with socket.socket() as sk:  # a port the kernel reports free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
     O = oracle
     rng = np.random.default_rng(1234)
