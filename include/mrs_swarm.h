@@ -229,6 +229,9 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s);
  * kd-tree, src/multirotor_simulator.cpp:303-317, which this replaces) */
 int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds);
 
+/* diagnostic hook: the eight control words of the collision pass's neighbour-list state machine (skin flags of the two tick
+ * parities, search counter, table-dirty flags, list-overflow counter — collide.hip); synchronises the stream.  tools/collision_words.py */
+int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8);
 /* test hook: runs the cascade kernels' own PID device function (PIDController::update, controllers/pid.hpp:67-96) over
  * caller-given sequences on the GPU, one lane per sequence — row-major [n_seq][n_steps] arrays; params = n_seq x
  * {kp, kd, ki, saturation, antiwindup}; event 1 = reset() before the update, 2 = setSaturation(new_sat) before it.

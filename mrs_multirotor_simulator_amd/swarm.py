@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
-    "mrs_debug_pid_sequences", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy",
+    "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -186,6 +186,7 @@ def load_library():
         "mrs_swarm_pack_positions_to": [vp, vp],
         "mrs_swarm_handle_collisions_gathered": [vp, vp, C.c_int64, C.c_int64, i32, i32, f64],
         "mrs_debug_pid_sequences": [i32, i32, i32, i32, dp, dp, dp, dp, dp, dp],
+        "mrs_swarm_debug_collision_words": [vp, C.POINTER(C.c_uint32)],
         "mrs_rccl_unique_id": [C.c_char_p, vp],
         "mrs_swarm_comm_init": [vp, C.c_char_p, i32, i32, vp, C.c_int64],
         "mrs_swarm_tick_sharded_n": [vp, f64, i32, i32, i32, f64],
