@@ -42,10 +42,7 @@ public:
 
 class AccelerationHdgRate {  // :147-169
 public:
-  AccelerationHdgRate(const Eigen::Vector3d& acceleration, const double& heading_rate) {
-    this->acceleration = acceleration;
-    this->heading_rate = heading_rate;
-  }
+  AccelerationHdgRate(const Eigen::Vector3d& acceleration_in, const double& heading_rate_in) : acceleration(acceleration_in), heading_rate(heading_rate_in) {}
   AccelerationHdgRate() { this->acceleration = Eigen::Vector3d::Zero(); }
   Eigen::Vector3d acceleration;
   double          heading_rate = 0;
@@ -53,10 +50,7 @@ public:
 
 class AccelerationHdg {  // :173-198
 public:
-  AccelerationHdg(const Eigen::Vector3d& acceleration, const double& heading) {
-    this->acceleration = acceleration;
-    this->heading      = heading;
-  }
+  AccelerationHdg(const Eigen::Vector3d& acceleration_in, const double& heading_in) : acceleration(acceleration_in), heading(heading_in) {}
   AccelerationHdg() { this->acceleration = Eigen::Vector3d::Zero(); }
   Eigen::Vector3d acceleration;
   double          heading = 0;
@@ -64,10 +58,7 @@ public:
 
 class VelocityHdgRate {  // :202-227
 public:
-  VelocityHdgRate(const Eigen::Vector3d& velocity, const double& heading_rate) {
-    this->velocity     = velocity;
-    this->heading_rate = heading_rate;
-  }
+  VelocityHdgRate(const Eigen::Vector3d& velocity_in, const double& heading_rate_in) : velocity(velocity_in), heading_rate(heading_rate_in) {}
   VelocityHdgRate() { this->velocity = Eigen::Vector3d::Zero(); }
   Eigen::Vector3d velocity;
   double          heading_rate = 0;
@@ -75,10 +66,7 @@ public:
 
 class VelocityHdg {  // :231-256
 public:
-  VelocityHdg(const Eigen::Vector3d& velocity, const double& heading) {
-    this->velocity = velocity;
-    this->heading  = heading;
-  }
+  VelocityHdg(const Eigen::Vector3d& velocity_in, const double& heading_in) : velocity(velocity_in), heading(heading_in) {}
   VelocityHdg() { this->velocity = Eigen::Vector3d::Zero(); }
   Eigen::Vector3d velocity;
   double          heading = 0;
