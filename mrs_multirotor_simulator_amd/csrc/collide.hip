@@ -482,6 +482,7 @@ template <bool LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
                                               double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id) {
+  (void)table_id;  // kept in the signature next to the insert kernels' one
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
   __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag

@@ -224,15 +224,15 @@ static void angle_axis_z(double angle, double R[9]) {
 
 // RCCL entry points, bound at run time by rccl_load() below
 namespace {
+struct NcclId { char internal[128]; };  // ncclUniqueId: NCCL_UNIQUE_ID_BYTES = 128, passed BY VALUE to ncclCommInitRank
 struct RcclApi {
   void* lib = nullptr;
-  int (*GetUniqueId)(void*)                                             = nullptr;
-  int (*CommInitRank)(void**, int, const void* /* by value, 128 B */, int) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t)  = nullptr;
-  int (*CommDestroy)(void*)                                              = nullptr;
-  const char* (*GetErrorString)(int)                                     = nullptr;
+  int (*GetUniqueId)(NcclId*)                                           = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int)                         = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*)                                             = nullptr;
+  const char* (*GetErrorString)(int)                                    = nullptr;
 };
-struct NcclId { char internal[128]; };
 RcclApi g_rccl;
 }  // namespace
 
@@ -1041,11 +1041,11 @@ int rccl_load(const char* path) {
   if (g_rccl.lib) return MRS_OK;
   void* lib = dlopen(path && *path ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return fail(MRS_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
-  g_rccl.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.GetUniqueId    = (int (*)(NcclId*))dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   g_rccl.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
-  *(void**)&g_rccl.CommInitRank = dlsym(lib, "ncclCommInitRank");
+  g_rccl.CommInitRank   = (int (*)(void**, int, NcclId, int))dlsym(lib, "ncclCommInitRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.CommInitRank) {
     g_rccl = RcclApi();
     dlclose(lib);
@@ -1083,8 +1083,7 @@ int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world,
   if (s->rccl_comm) return fail(MRS_ERR_ARG, "communicator already initialised");
   NcclId id;
   memcpy(id.internal, id128, 128);
-  typedef int (*init_fn)(void**, int, NcclId, int);
-  if ((rc = rccl_check(((init_fn)g_rccl.CommInitRank)(&s->rccl_comm, world, id, rank), "ncclCommInitRank"))) return rc;
+  if ((rc = rccl_check(g_rccl.CommInitRank(&s->rccl_comm, world, id, rank), "ncclCommInitRank"))) return rc;
   s->comm_world   = world;
   s->comm_rank    = rank;
   s->comm_n_total = n_total;
