@@ -969,3 +969,44 @@ def test_device_pid_reproduces_the_reference_pid_vectors(M):
     ok = np.isfinite(exp)
     scale = np.maximum(1.0, np.max(np.where(ok, np.abs(exp), 0.0), axis=1, keepdims=True))
     assert np.max(np.abs(fast[ok] - exp[ok]) / np.broadcast_to(scale, exp.shape)[ok]) < 1e-12
+
+
+def test_non_temporal_kernel_matches_the_ordinary_one(M):
+    """Model-only steps of small swarms run the `*_buf_nt` kernel (non-temporal state accesses, step_device.inc); the launcher's
+    choice can be forced either way per process (MRS_NT_ACCESSES), so both run in child processes on the same actuator-level
+    swarm, single- and two-stream runs included.  A cache hint must not change a bit in LITERAL; in FAST the two instantiations
+    may contract differently (last bits)."""
+    import subprocess, sys, json
+    code = r'''
+import json, numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mrs_multirotor_simulator_amd as M
+import helpers
+rng = np.random.default_rng(31)
+n = 70000  # 1094 blocks: enough for the two-stream form of a long run
+out = {}
+for arith in (M.ARITH_LITERAL, M.ARITH_FAST):
+    g = M.Swarm(n, arith=arith)
+    st = helpers.random_state(rng, n, 4, tilted=True)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(n))
+    g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    g.set_input(0, n, M.ACTUATOR_CMD, rng.uniform(0.3, 0.6, (n, 4)))
+    g.step_n(0.001, 3)    # single stream
+    g.step_n(0.001, 40)   # two streams
+    s = g.get_state(0, 4096)
+    t = g.get_state(n - 4096, 4096)
+    out[str(arith)] = {k: np.concatenate([s[k], t[k]]).tolist() for k in ("x", "v", "R", "omega", "motor_rpm")}
+print("RESULT" + json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for nt in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MRS_NT_ACCESSES=nt), timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0][6:]))
+    for arith in res[0]:
+        for k in res[0][arith]:
+            a, b = np.array(res[0][arith][k]), np.array(res[1][arith][k])
+            if int(arith) == M.ARITH_LITERAL:
+                assert np.array_equal(a, b), f"literal: {k}"
+            else:
+                helpers.assert_close(a, b, RTOL_FAST, f"fast: {k}")
