@@ -60,14 +60,14 @@ def parse():
 
 
 def make_inputs(n, workload, seed, volume_per_uav=64.0):
-    import helpers
+    from mrs_multirotor_simulator_amd import synthetic  # numpy only: the GPU legs of the bench never touch oracle/ or tests/
     rng = np.random.default_rng(seed)
     if workload == "actuator":
-        st = helpers.random_state(rng, n, 4)
+        st = synthetic.random_state(rng, n, 4)
         cmd = rng.uniform(0.35, 0.60, (n, 4))
     else:
         side = (volume_per_uav * n) ** (1.0 / 3.0)  # 64 m^3 per UAV by default (BASELINE config 4)
-        st = helpers.random_state(rng, n, 4, tilted=True)
+        st = synthetic.random_state(rng, n, 4, tilted=True)
         st["x"] = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
         cmd = np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
     return st, cmd

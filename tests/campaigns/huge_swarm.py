@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One-off capacity check: a swarm far beyond the 4 GiB reach of buffer addressing (default 50 M UAVs = 34 GB of state), built as
 copies of a 4096-UAV swarm; every copy must stay bit-identical to the first one and the first one must follow the oracle.
-usage: tools/huge_swarm.py [n_uavs] [steps]   (host memory needed: about 1 kB per UAV)"""
+usage: tests/campaigns/huge_swarm.py [n_uavs] [steps]   (host memory needed: about 1 kB per UAV)"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 import mrs_multirotor_simulator_amd as M

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """300 more random call sequences of tests/test_random_sequences_gpu.py (seeds 100-399), outside the test suite."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib
 import mrs_multirotor_simulator_amd as mrs

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Long differential run: a dense, moving swarm with elastic collisions, position commands that change, occasional crashes and
 holds — product (tick_n) vs oracle (step + handle_collisions per tick), compared every `chunk` ticks.
-usage: tools/soak.py [n_uavs] [n_ticks] [literal|fast] [m^3 per UAV] [local|sharded]
+usage: tests/campaigns/soak.py [n_uavs] [n_ticks] [literal|fast] [m^3 per UAV] [local|sharded]
 `sharded` drives the ticks through mrs_swarm_tick_sharded_n with a one-rank RCCL communicator (the multi-GPU code path)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from helpers import Pair

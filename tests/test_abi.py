@@ -3,6 +3,7 @@ include/mrs_swarm.h declares, and its host-only helpers agree with the oracle.  
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -64,3 +65,22 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle's", "").replace("oracle/", "ORACLE_DOC/") or "import oracle" not in txt
                 assert "liboracle" not in txt and "uav_oracle" not in txt and "from oracle" not in txt
+
+
+def test_bench_reaches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py may use oracle/ for the `cpu_baseline` leg alone: importing the module and generating the synthetic inputs of every
+    workload must leave `oracle` (and tests/helpers, which imports it) unloaded, and the only functions of bench.py that mention
+    them are cpu_baseline and its helpers."""
+    import subprocess
+    code = ("import sys; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "for w in ('actuator', 'position', 'position+collisions'): bench.make_inputs(256, w, 3)\n"
+            "bad = [m for m in sys.modules if m == 'helpers' or m == 'oracle' or m.startswith('oracle.')]\n"
+            "assert not bad, bad\nprint('clean')") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "clean" in out.stdout, out.stderr[-1500:]
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        src = ast.get_source_segment(open(os.path.join(ROOT, "bench.py")).read(), fn)
+        if "from oracle" in src or "import helpers" in src:
+            assert fn.name == "cpu_baseline", f"{fn.name} reaches for the oracle"

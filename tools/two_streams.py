@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers
+from mrs_multirotor_simulator_amd import synthetic as helpers  # numpy-only state generators
 import mrs_multirotor_simulator_amd as M
 DT = 0.001
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
