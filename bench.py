@@ -249,6 +249,8 @@ def main():
         }
         if coll:
             out["roofline"]["note"] = "per-kernel times of the tick: profiles/r01_collision_tick_100k_kernel_stats.csv"
+            ticks, searches = sw.collision_stats()
+            out["config"]["collision_ticks"], out["config"]["neighbour_searches"] = int(ticks), int(searches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, st, cmd)
         print(json.dumps(out), flush=True)
