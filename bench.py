@@ -221,7 +221,7 @@ def main():
         kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
         if 86 * npad * 8 < 2 ** 32:
             fast1 = args.substeps == 1 and args.arith == "fast"
-            kernel_name += "_buf" + ("_w3" if (fast1 and npad // 64 > 2048) else "_nt" if (fast1 and args.workload == "actuator" and npad // 64 <= 1900) else "")
+            kernel_name += "_buf" + ("_w3" if (fast1 and npad // 64 > 2048) else "_nt" if (fast1 and npad // 64 <= (1900 if args.workload == "actuator" else 900)) else "")
         kernel_name += "_" + args.arith
         # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1
