@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — UAV-steps/sec of the fused UavSystem::makeStep() kernel on N MI355X (one process per GPU).
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through torch.distributed.run.
-A "step" is one makeStep(dt = 1 ms) of every UAV of the rank's shard (one kernel launch over the whole batch, state
-resident in HBM).  Workload at every N: BASELINE.json configs[2] — 100 000 x500 UAVs per GPU, actuator-level references,
-no collisions (weak scaling: UAVs are independent, no data-path collective).  Rank 0 prints ONE JSON line.
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 the driver launches it through torch.distributed.run,
+and a PLAIN `python bench.py --gpus N` starts those N ranks itself (a torch.distributed.run child, before this process touches a GPU).
+A "step" is one makeStep(dt = 1 ms) of every UAV of the rank's shard (one kernel launch over the whole batch, state resident in
+HBM).  Headline workload at every N: BASELINE.json configs[2] — 100 000 x500 UAVs per GPU, actuator-level references, no
+collisions (weak scaling: UAVs are independent, no data-path collective).  For N > 1 the same JSON line carries a `config5`
+sub-record: BASELINE configs[4], 1 000 000 UAVs with mutual collisions sharded over the N ranks, the collision exchange over RCCL.
+Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced with MAX
+over ranks.  One region of the driver's K = 20 lasts 0.2 ms, a quarter of it host latency, so regions are repeated until 50 ms have
+been measured and `ms_per_step` / `value` come from the MEDIAN region (`regions`, `first_region_ms_per_step` are reported too).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,28 +28,41 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 DT = 0.001
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0  # what a plain read+write stream reaches according to the same guide (measured here: 6.0-6.2 TB/s)
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
+STATE_BYTES_PER_UAV = 86 * 8 + 4  # swarm_layout.h: F_COUNT doubles + the flag word
 
 # algorithmic bytes per UAV-step: one read + one write of everything the step must touch, FP64
 BYTES_PER_UAV_STEP = {
     "actuator": (25 + 3 + 4 + 1) * 8 + 4 + (25 + 3) * 8,            # 492 B  (n_motors = 4)
     "position": (25 + 3 + 1 + 24 + 4) * 8 + 4 + (25 + 3 + 24) * 8,  # 876 B
 }
+# what the kernels really move per UAV-step: the v_prev, F_ext (while no force was ever applied) and init_z columns are elided
+# (DESIGN §4): read x v R w (18) + cmd 4 + rpm 4 + flags, write x v R w + imu 3 + rpm 4 — and the 24 PID doubles both ways
+BYTES_MOVED_PER_UAV_STEP = {"actuator": (18 + 4 + 4) * 8 + 4 + (18 + 3 + 4) * 8,                # 412 B (PMC: 417)
+                            "position": (18 + 4 + 4 + 24) * 8 + 4 + (18 + 3 + 4 + 24) * 8}      # 796 B
+# collision pass: a list tick reads the list head + count and writes the force for every UAV, and gathers the
+# positions of the listed partners of the p UAVs that have any; a search tick is the SURVEY figure
+COLLISION_BYTES = {"list_tick_per_uav": 28, "list_tick_per_uav_with_partner": 150, "search_tick_per_uav": 92, "search_tick_per_candidate": 24}
 
 
 def pmc_traffic(args, n):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC summary of this same command (profiles/), corrected as
+    """HBM-side bytes per launch from a committed rocprofv3 PMC summary of this same command (profiles/), corrected as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950 (confirmed by the calibration rows of that summary for this
     8-B/lane SoA pattern), WRITE_SIZE exact, both x1024.  None when no summary matches the configuration."""
     stem = {"actuator": "step_kernel", "position": "position_cascade"}.get(args.workload)
     size = f"{n // 1000}k" if n < 1_000_000 else f"{n // 1_000_000}M"
-    path = os.path.join(ROOT, "profiles", f"r01_{stem}_{size}_{args.arith}_summary.json")
-    if stem is None or args.substeps != 1 or not os.path.exists(path):
+    if stem is None or args.substeps != 1:
         return None, None
-    pmc = json.load(open(path)).get("pmc", {})
-    if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
-        return None, None
-    return (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}_{size}_{args.arith}_summary.json")
+        if not os.path.exists(path):
+            continue
+        pmc = json.load(open(path)).get("pmc", {})
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            return (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def parse():
@@ -56,7 +78,27 @@ def parse():
     ap.add_argument("--substeps", type=int, default=1, help="makeStep rounds fused per launch (state kept in registers)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-measure-ms", type=float, default=50.0, help="regions of --steps steps are repeated until this much was timed")
+    ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
+                    help="the 1 000 000-UAV collision leg (BASELINE configs[4]); auto = whenever N > 1")
+    ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly: run the N ranks as a torch.distributed.run CHILD (this process has not touched
+    the GPU: device_count() does not initialise it on this image) and leave with its exit code."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def make_inputs(n, workload, seed, volume_per_uav=64.0):
@@ -75,9 +117,10 @@ def make_inputs(n, workload, seed, volume_per_uav=64.0):
 
 def cpu_baseline(args, st, cmd):
     """The oracle (scalar C restatement of the reference, 1 thread like the reference's serial loop) timed on a bounded
-    sample of the same workload."""
-    import helpers
+    sample of the same workload, built for this host with the flags SURVEY §8d names."""
     from oracle import oracle_swarm as O
+    flags = O.use_native()  # -O3 -march=native -ffp-contract=off, compiled on this machine (falls back to the portable -O2 build)
+    import helpers
     n = min(args.uavs, 20_000)
     o = O.OracleSwarm(n)
     po = helpers.oracle_params("x500", ground_enabled=True)
@@ -100,8 +143,8 @@ def cpu_baseline(args, st, cmd):
         el = time.perf_counter() - t0
         if el > args.cpu_seconds:
             break
-    out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c -O2 -ffp-contract=off, 1 thread "
+    out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port", "compiler_flags": "gcc " + flags,
+           "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c ({flags}), 1 thread "
                      "(the reference's loop is serial, src/multirotor_simulator.cpp:211-213)"}
     if coll and O.ref_lib() is not None:
         # the reference's OWN broadphase on the same positions: nanoflann build + one radius search per UAV
@@ -124,57 +167,81 @@ def cpu_baseline(args, st, cmd):
     return out
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+class Ranks:
+    """what a leg needs of the process group: rank/world, barrier, MAX over ranks"""
 
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+        if self.local >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: local rank {self.local} has no GPU ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(self.local)
+        self.use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched through torch.distributed.run
+        if self.use_dist:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+
+    def barrier(self, sync_local):
+        sync_local()
+        if self.use_dist:
+            self.dist.barrier()
+        sync_local()
+
+    def max_over_ranks(self, x):
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_regions(R, run, sync_local, steps, warmup, min_ms, after_region=None):
+    """W warm-up steps, then regions of exactly `steps` steps (barrier + synchronize on both sides, MAX over ranks) until min_ms have
+    been timed.  Returns the per-region seconds."""
+    run(warmup)
+    R.barrier(sync_local)
+    if R.use_dist:
+        R.barrier(sync_local)  # the first RCCL barrier of a process sets up its communicator (milliseconds): keep that out of the start skew
+    times, extra = [], []
+    while True:
+        R.barrier(sync_local)
+        t0 = time.perf_counter()
+        run(steps)
+        # closing bracket: every rank's K steps are complete at its own synchronize — that instant ends ITS interval; the barrier
+        # of the next region (an RCCL kernel + host round trip of ~1-2 ms, not part of the workload) follows, MAX over ranks closes it
+        sync_local()
+        el = time.perf_counter() - t0
+        if after_region is not None:
+            extra.append(after_region())
+        times.append(R.max_over_ranks(el))  # identical on every rank: all ranks take the same number of regions
+        if sum(times) * 1e3 >= min_ms or len(times) >= 400:
+            break
+    return times, extra
+
+
+def headline_leg(args, R):
     import mrs_multirotor_simulator_amd as M
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
-    torch.cuda.set_device(local)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched through torch.distributed.run
-    if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
+    torch = R.torch
     n = args.uavs
-    st, cmd = make_inputs(n, args.workload, seed=3 + rank, volume_per_uav=args.volume_per_uav)
-    sw = M.Swarm(n, device=local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
+    st, cmd = make_inputs(n, args.workload, seed=3 + R.rank, volume_per_uav=args.volume_per_uav)
+    sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
     sw.construct(0, n, M.model_params("x500", ground_enabled=True))
     sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
     sw.set_input(0, n, M.ACTUATOR_CMD if args.workload == "actuator" else M.POSITION_CMD, cmd)
     coll = args.workload.endswith("collisions")
 
-    sharded = None
-    native_comm = False
-    force_comm = os.environ.get("MRS_NATIVE_RCCL") == "force"  # rehearse the multi-rank code path with a one-rank communicator
-    if coll and (world > 1 or force_comm):  # BASELINE configs[4]: index shards + ONE all-gather of 48-B records per tick (RCCL over xGMI)
-        if os.environ.get("MRS_NATIVE_RCCL", "1") != "0":
-            # the library issues the all-gather itself on the swarm's stream (mrs_swarm_tick_sharded_n): K ticks = one host call
-            from mrs_multirotor_simulator_amd.swarm import rccl_unique_id
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).cuda()
-            if use_dist:
-                dist.broadcast(uid, 0)
-            sw.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()), n * world)
-            native_comm = True
-            sharded = sw
-        else:  # the same exchange driven from Python through torch.distributed (sharded.py)
-            from mrs_multirotor_simulator_amd.sharded import GpuEngine, ShardedSwarm
-            dev = torch.device("cuda", local)
-            sharded = ShardedSwarm(n * world, GpuEngine(sw, dev), dev)
-
     def run(k):
-        if native_comm:
-            sw.tick_sharded_n(DT, k, True, False, 100.0)
-        elif sharded is not None:
-            sharded.tick_n(DT, k, True, False, 100.0)
-        elif coll:
+        if coll:
             sw.tick_n(DT, k, True, False, 100.0)
         else:
             sw.step_n(DT, k, args.substeps)
@@ -183,37 +250,21 @@ def main():
         sw.synchronize()
         torch.cuda.synchronize()
 
-    def barrier():
-        sync_local()
-        if use_dist:
-            dist.barrier()
-        sync_local()
-
-    run(args.warmup)
-    barrier()
-    if use_dist:
-        barrier()  # the first RCCL barrier of a process sets up its communicator (milliseconds): keep that out of the start skew
-    sw.set_profiling(0 if sharded is not None else 1)  # one hipEvent pair around the timed region, on the swarm's stream
-    t0 = time.perf_counter()
-    run(args.steps)
-    # closing bracket: every rank's K steps are complete at its own synchronize — that instant ends ITS interval; the barrier that
-    # follows (an RCCL kernel + host round trip of ~1-2 ms, not part of the workload) and the MAX over ranks close the job's interval
-    sync_local()
-    el = time.perf_counter() - t0
-    barrier()
-    kern_ms, n_launch = sw.last_step_kernel_ms() if sharded is None else (el / args.steps * 1e3, args.steps)
+    sw.set_profiling(1)  # one hipEvent pair around every step_n / tick_n call, on the swarm's stream
+    times, ev = timed_regions(R, run, sync_local, args.steps, args.warmup, args.min_measure_ms, after_region=sw.last_step_kernel_ms)
     sw.set_profiling(0)
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
     assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
-    if rank == 0:
+    el = float(np.median(times))
+    kern_ms = float(np.median([e[0] for e in ev]))
+    n_launch = ev[0][1]
+    out = None
+    if R.rank == 0:
+        world = R.world
         key = "actuator" if args.workload == "actuator" else "position"
         # one launch reads and writes the state once, however many sub-steps it fuses: no roofline credit for fusion
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        moved = BYTES_MOVED_PER_UAV_STEP[key] * n / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args, n)
         # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
         # non-temporal accesses for model-only steps of small swarms
@@ -229,36 +280,113 @@ def main():
             launches_per_step = 2
         if traffic is not None:
             traffic *= launches_per_step  # the PMC summary is per dispatch; `achieved` and `traffic` are both per step
+        touched = STATE_BYTES_PER_UAV * n
         out = {
             "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "regions": len(times), "first_region_ms_per_step": times[0] / args.steps * 1e3,
+            "timing": f"median of {len(times)} regions of {args.steps} steps, each bracketed by barrier + synchronize and MAX-reduced over ranks",
             "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {args.workload} references, dt=1 ms, RK4, ground on"
                        if args.workload == "actuator" else f"{n} x500 UAVs per GPU, {args.workload}, dt=1 ms",
                        "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
-                       "parallelism": (f"{world} index shards, one all-gather of 48 B/UAV per tick" if (coll and (world > 1 or native_comm))
-                                       else f"{world} independent shard(s), no collective")},
+                       "parallelism": f"{world} independent shard(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name if not coll
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "regime": "infinity-cache-resident" if touched < INFINITY_CACHE_BYTES else "hbm-streaming",
+                         "touched_bytes": touched,
+                         "bytes_moved_per_uav_step": BYTES_MOVED_PER_UAV_STEP[key], "moved_GBps": moved,
+                         "frac_moved_of_peak": moved / HBM_PEAK_GBS,
+                         "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": moved / HBM_ACHIEVABLE_GBS,
+                         "kernel": kernel_name if not coll
                          else "whole tick: " + kernel_name + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
                          "concurrent_launches_per_step": launches_per_step,
-                         "method": "one hipEvent pair around the timed region on the swarm's stream (the second stream is joined before the closing "
-                                   "event): elapsed / steps, inter-launch gaps included; with two concurrent half-swarm launches per step `achieved` "
-                                   "is the bytes of both over that time, and each launch lasts about one step period (rocprofv3 per-dispatch average)"},
+                         "method": "one hipEvent pair around each timed region on the swarm's stream (the second stream is joined before the closing "
+                                   "event): elapsed / steps, inter-launch gaps included, median over the regions; with two concurrent half-swarm launches "
+                                   "per step `achieved` is the bytes of both over that time.  `achieved` prices the ALGORITHMIC bytes (SURVEY 8d); "
+                                   "`moved_GBps` the bytes the kernel really moves (elided v_prev / F_ext / init_z columns), and `frac_of_achievable` "
+                                   "holds those against the 6.3 TB/s a read+write stream reaches.  In the `infinity-cache-resident` regime the state "
+                                   "(touched_bytes) fits the 256 MiB Infinity Cache, so HBM bandwidth is not the operative limit there — "
+                                   "profiles/ holds the hbm-streaming runs (>= 4 M UAVs)"},
         }
         if coll:
-            out["roofline"]["note"] = "per-kernel times of the tick: profiles/r01_collision_tick_100k_kernel_stats.csv"
             ticks, searches = sw.collision_stats()
             out["config"]["collision_ticks"], out["config"]["neighbour_searches"] = int(ticks), int(searches)
+            p = 0.06  # fraction of UAVs with a listed partner at 64 m^3 per UAV
+            cb = COLLISION_BYTES["list_tick_per_uav"] + COLLISION_BYTES["list_tick_per_uav_with_partner"] * p
+            out["roofline_collision"] = {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "algorithmic_bytes_per_uav_list_tick": cb, "algorithmic_bytes_per_uav_search_tick": "92 + 24 * candidates",
+                "achieved_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9,
+                "frac_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "whole tick = step + collision pass over (step bytes + list-tick bytes); per-kernel times: profiles/r02_collision_tick_*"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, st, cmd)
+    del sw
+    return out
+
+
+def config5_leg(args, R):
+    """BASELINE configs[4]: `--config5-uavs` UAVs (1 000 000) with mutual collisions, sharded over the ranks; the collision exchange is
+    issued by the library itself on the swarm's stream (mrs_swarm_tick_sharded_n: RCCL bound at run time)."""
+    import mrs_multirotor_simulator_amd as M
+    from mrs_multirotor_simulator_amd.sharded import shard_range
+    from mrs_multirotor_simulator_amd.swarm import rccl_unique_id
+    torch, dist = R.torch, R.dist
+    n_total = args.config5_uavs
+    lo, hi = shard_range(n_total, R.world, R.rank)
+    n = hi - lo
+    st, cmd = make_inputs(n_total, "position+collisions", seed=5, volume_per_uav=args.volume_per_uav)  # every rank draws the same swarm
+    sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
+    sw.construct(0, n, M.model_params("x500", ground_enabled=True))
+    sw.set_state(0, n, st["x"][lo:hi], st["v"][lo:hi], st["R"][lo:hi], st["omega"][lo:hi], st["motor_rpm"][lo:hi])
+    sw.set_input(0, n, M.POSITION_CMD, cmd[lo:hi])
+    del st, cmd
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if R.rank == 0:
+        uid = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).cuda()
+    if R.use_dist:
+        dist.broadcast(uid, 0)
+    sw.comm_init(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()), n_total)
+
+    def run(k):
+        sw.tick_sharded_n(DT, k, True, False, 100.0)
+
+    def sync_local():
+        sw.synchronize()
+        torch.cuda.synchronize()
+
+    steps, warmup = args.steps, min(args.warmup, 50)
+    times, _ = timed_regions(R, run, sync_local, steps, warmup, args.min_measure_ms)
+    el = float(np.median(times))
+    info = sw.comm_info()
+    ticks, searches = sw.collision_stats()
+    out = {"workload": f"BASELINE configs[4]: {n_total} x500 UAVs, position references + mutual collisions (64 m^3 per UAV), {R.world} shards",
+           "value": n_total * steps / el, "unit": "UAV-steps/s", "ms_per_tick": el / steps * 1e3, "n_total": n_total, "n_gpus": R.world,
+           "steps": steps, "warmup": warmup, "regions": len(times), "scaling": "strong",
+           "parallelism": info["parallelism"], "rccl_ranks": info["rccl_ranks"],
+           "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collision_ticks": int(ticks), "neighbour_searches": int(searches)}
+    sw.comm_destroy()
+    del sw
+    return out if R.rank == 0 else None
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    R = Ranks()
+    if R.world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {R.world} rank(s)")
+    out = headline_leg(args, R)
+    if args.config5 == "on" or (args.config5 == "auto" and R.world > 1):
+        c5 = config5_leg(args, R)
+        if R.rank == 0:
+            out["config5"] = c5
+    if R.rank == 0:
         print(json.dumps(out), flush=True)
-    if native_comm:
-        sw.comm_destroy()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

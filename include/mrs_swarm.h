@@ -223,6 +223,19 @@ int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128);
 int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total);
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
 int mrs_swarm_comm_destroy(mrs_swarm_t* s);
+/* what the communicator of this swarm looks like: ranks as mrs_swarm_comm_init was told and as RCCL itself counts them
+ * (ncclCommCount), the exchange in use and the bytes every rank contributes to the per-tick collective */
+typedef struct {
+  int32_t world, rank;
+  int32_t rccl_ranks;       /* ncclCommCount of the communicator (0: no RCCL communicator, e.g. an in-process loopback group) */
+  int32_t exchange;         /* MRS_EXCHANGE_* */
+  int64_t n_total;
+  int64_t bytes_per_tick;   /* bytes this rank sends into the collision collective of an ordinary tick */
+  int64_t bytes_per_rebuild; /* bytes it sends on a tick that repeats the neighbour search (export-set exchange only) */
+  int64_t export_count, export_capacity; /* export-set exchange: own UAVs some other rank lists / slots of the padded collective */
+} mrs_comm_info_t;
+enum { MRS_EXCHANGE_NONE = 0, MRS_EXCHANGE_FULL_GATHER = 1, MRS_EXCHANGE_EXPORT_SETS = 2 };
+int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out);
 
 /* collision-pass statistics of mrs_swarm_handle_collisions / mrs_swarm_tick_n: ticks that ran the pass, and how many of them had to
  * repeat the neighbour search (the others reused the neighbour lists of an earlier tick — same results as the reference's per-tick

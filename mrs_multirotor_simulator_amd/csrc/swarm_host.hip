@@ -231,6 +231,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, NcclId, int)                         = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*)                                             = nullptr;
+  int (*CommCount)(void*, int*)                                         = nullptr;
   const char* (*GetErrorString)(int)                                    = nullptr;
 };
 RcclApi g_rccl;
@@ -1046,6 +1047,7 @@ int rccl_load(const char* path) {
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   g_rccl.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
   g_rccl.CommInitRank   = (int (*)(void**, int, NcclId, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.CommCount      = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
   if (!g_rccl.GetUniqueId || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.CommInitRank) {
     g_rccl = RcclApi();
     dlclose(lib);
@@ -1106,6 +1108,25 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   if (s->comm_recv) (void)hipFree(s->comm_recv);
   s->comm_send = s->comm_recv = nullptr;
   return rc;
+}
+
+int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
+  MRS_LOCK(s);
+  if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
+  memset(out, 0, sizeof *out);
+  if (!s->rccl_comm) return MRS_OK;
+  out->world    = s->comm_world;
+  out->rank     = s->comm_rank;
+  out->n_total  = s->comm_n_total;
+  out->exchange = MRS_EXCHANGE_FULL_GATHER;
+  out->bytes_per_tick = (int64_t)sizeof(PosRecord) * s->comm_n_max;
+  if (g_rccl.CommCount) {
+    int c = 0;
+    int rc = rccl_check(g_rccl.CommCount(s->rccl_comm, &c), "ncclCommCount");
+    if (rc) return rc;
+    out->rccl_ranks = c;
+  }
+  return MRS_OK;
 }
 
 // timerMain on every rank of a sharded swarm: step, pack, ONE all-gather of the 48-B records on the swarm's own stream, collision

@@ -60,6 +60,15 @@ OUTPUT_DTYPE = np.dtype([("position", "f8", 3), ("orientation", "f8", 4), ("velo
                          ("angular_velocity", "f8", 3), ("linear_acceleration", "f8", 3), ("range", "f8")])
 
 
+class CommInfo(C.Structure):
+    """mrs_comm_info_t"""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("rccl_ranks", C.c_int32), ("exchange", C.c_int32), ("n_total", C.c_int64),
+                ("bytes_per_tick", C.c_int64), ("bytes_per_rebuild", C.c_int64), ("export_count", C.c_int64), ("export_capacity", C.c_int64)]
+
+
+EXCHANGE_NAMES = {0: "none", 1: "full all-gather of 48-B records per tick", 2: "export-set all-gather (boundary UAVs only), full gather on search ticks"}
+
+
 class Diag(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("hdg_rate_denom_small", "projected_norm_small", "yaw_rate_not_finite",
                                           "nan_rollback")]
@@ -76,7 +85,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_has_crashed", "mrs_swarm_step", "mrs_swarm_step_n", "mrs_swarm_handle_collisions", "mrs_swarm_tick_n",
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
-    "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy",
+    "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -191,6 +200,7 @@ def load_library():
         "mrs_swarm_comm_init": [vp, C.c_char_p, i32, i32, vp, C.c_int64],
         "mrs_swarm_tick_sharded_n": [vp, f64, i32, i32, i32, f64],
         "mrs_swarm_comm_destroy": [vp],
+        "mrs_swarm_comm_info": [vp, C.POINTER(CommInfo)],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -377,6 +387,13 @@ class Swarm:
 
     def comm_destroy(self):
         _check(_lib.mrs_swarm_comm_destroy(self._h))
+
+    def comm_info(self):
+        ci = CommInfo()
+        _check(_lib.mrs_swarm_comm_info(self._h, C.byref(ci)))
+        d = {k: int(getattr(ci, k)) for k, _ in CommInfo._fields_}
+        d["parallelism"] = f"{d['world']} index shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, RCCL"
+        return d
 
     # -- state --
     def get_state(self, first=0, count=None):

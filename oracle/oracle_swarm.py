@@ -70,12 +70,29 @@ def build(force=False):
 
 
 _lib = None
+_lib_path = None
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math"
+PORTABLE_FLAGS = "-O2 -ffp-contract=off -fno-fast-math"
+
+
+def use_native():
+    """bench.py's cpu_baseline leg: build oracle/_native/liboracle_native.so with -O3 -march=native ON THIS MACHINE and make it the
+    library behind OracleSwarm (must be called before the first lib() call).  Returns the compiler flags of the library in use."""
+    global _lib_path
+    assert _lib is None, "use_native() must come before the oracle library is loaded"
+    so = os.path.join(HERE, "_native", "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib_path = so
+        return NATIVE_FLAGS
+    except (OSError, subprocess.CalledProcessError):
+        return PORTABLE_FLAGS
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(_lib_path or build())
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         L = _lib
         L.orc_swarm_create.restype = C.c_void_p

@@ -64,6 +64,9 @@ class Pair:
         worst = 0.0
         for k in tuple(fields) + ("imu", "pid"):
             worst = max(worst, assert_close(a[k], b[k], rtol, f"{what}:{k}"))
+        # north_star's measure is the state-vector L-inf of each UAV, not of the swarm: a UAV near the origin must not hide
+        # behind the coordinates of one 500 m away
+        self.worst_uav = assert_close_per_uav(a, b, rtol, what)
         return worst
 
 
@@ -81,6 +84,42 @@ def rel_linf(a, b):
     scale = np.max(np.abs(b[m]))
     diff = np.max(np.abs(a[m] - b[m]))
     return 0.0 if diff == 0 else diff / max(scale, 1e-300)
+
+
+# per-UAV measures -------------------------------------------------------------------------------------------------
+STATE_FIELDS = ("x", "v", "R", "omega", "motor_rpm")  # MultirotorModel::State, multirotor_model.hpp:90-98 (v_prev is a copy of v)
+# below these magnitudes a field is compared absolutely (a hovering UAV has v = omega = 0 exactly: no relative measure exists there)
+FIELD_FLOOR = {"x": 1.0, "v": 1.0, "v_prev": 1.0, "R": 1.0, "omega": 1.0, "motor_rpm": 1000.0, "imu": 9.81, "pid": 1.0, "f": 1.0}
+
+
+def per_uav_linf(a, b, fields=STATE_FIELDS):
+    """Two per-UAV relative L-inf errors of a state dict `a` against the reference `b` (arrays [n, ...]):
+      state : max_c |a_c - b_c| / max(||state_i||_inf, 1)   — the whole state vector of UAV i (north_star, literally)
+      field : max over fields of  max_c |a_c - b_c| / max(||field_i||_inf, floor_field)   — every field on its own scale (stricter:
+              the rpm entries ~4000 do not set the scale for R or omega)
+    NaN / inf patterns must match exactly.  Returns (state_err[n], field_err[n])."""
+    n = len(np.asarray(b[fields[0]]))
+    num_state, den_state, field_err = np.zeros(n), np.ones(n), np.zeros(n)
+    for k in fields:
+        x, y = np.asarray(a[k], dtype=np.float64).reshape(n, -1), np.asarray(b[k], dtype=np.float64).reshape(n, -1)
+        bad = ~np.isfinite(y)
+        assert np.array_equal(np.isnan(x), np.isnan(y)), f"{k}: NaN pattern differs"
+        assert np.array_equal(x[bad & ~np.isnan(y)], y[bad & ~np.isnan(y)]), f"{k}: inf pattern differs"
+        d = np.where(bad, 0.0, np.abs(np.where(bad, 0.0, x) - np.where(bad, 0.0, y))).max(axis=1)
+        m = np.where(bad, 0.0, np.abs(y)).max(axis=1)
+        num_state, den_state = np.maximum(num_state, d), np.maximum(den_state, m)
+        field_err = np.maximum(field_err, d / np.maximum(m, FIELD_FLOOR.get(k, 1.0)))
+    return num_state / den_state, field_err
+
+
+def assert_close_per_uav(a, b, rtol, what="", fields=STATE_FIELDS):
+    """every UAV's own state vector within rtol (both measures of per_uav_linf); returns (worst UAV, its field error)"""
+    se, fe = per_uav_linf(a, b, fields)
+    i = int(np.argmax(fe))
+    assert fe[i] <= rtol, (f"{what}: UAV {i} is off by {fe[i]:.3e} > {rtol:.1e} relative to its own fields "
+                           f"(state-vector measure {se[i]:.3e}; worst state-vector UAV {int(np.argmax(se))}: {se.max():.3e})")
+    assert se.max() <= rtol
+    return i, float(fe[i])
 
 
 def assert_close(a, b, rtol, what=""):
