@@ -19,7 +19,7 @@ UNITS = [
     ("outputs.hip", "off"),
     ("swarm_host.hip", "off"),
 ]
-DEPS = ["step_device.inc", "swarm_layout.h", os.path.join("..", "..", "include", "mrs_swarm.h")]
+DEPS = ["step_device.inc", "collide_device.inc", "swarm_layout.h", os.path.join("..", "..", "include", "mrs_swarm.h")]
 
 
 def _hipcc():

@@ -32,8 +32,10 @@
 // the pass in rebuild mode.  Results are identical to searching every tick.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "swarm_layout.h"
+#include "collide_device.inc"
 
 namespace {
 
@@ -43,7 +45,7 @@ constexpr double INV_CELL      = 1.0 / 1.75;  // plain search: edge 1.75 m > sqr
 constexpr double SKIN          = 0.5;         // neighbour lists: how far apart beyond sqrt(3) a listed pair may be
 constexpr double INV_CELL_WIDE = 1.0 / 2.25;  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508
 constexpr double LIST_R2       = 4.9821;      // > (sqrt(3) + SKIN)^2 = 4.98205...
-constexpr double POS_LIMIT     = 1.0e9;       // |coordinate| beyond this (or non-finite) never collides here
+constexpr double POS_LIMIT     = MRS_POS_LIMIT;  // |coordinate| beyond this (or non-finite) never collides here
 constexpr int    LIST_CAP      = 24;          // listed neighbours per UAV (0.7 expected at 64 m^3 per UAV, 4.6 at 10 m^3: P(> 24) ~ 1e-11;
                                               // with 8, one UAV in 10^4 overflowed at 30 m^3 per UAV and kept a 100 k swarm searching)
 
@@ -125,39 +127,9 @@ __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask,
 }
 
 // ---- query ----
-// accumulate one partner into the force / crash state of a UAV (literal predicate and force expression)
-__device__ __forceinline__ void apply_partner(const PosRecord& me, const PosRecord& o, int crash, double rebounce, double& fx, double& fy,
-                                              double& fz, bool& crashed) {
-  const double d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
-  const double dist    = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
-  const double crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
-  const double crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
-  if (crash) {
-    // the reference crashes the partner of every qualifying ordered pair (i -> idx); seen from the partner's side:
-    // this UAV is crashed iff some j has it as a qualifying partner, i.e. dist < crit(j, i)
-    if (dist < crit_ji) crashed = true;
-  } else if (dist < crit_ij) {
-    double r0 = d0, r1 = d1, r2 = d2;
-    const double z = (r0 * r0 + r1 * r1) + r2 * r2;  // Eigen normalized()
-    if (z > 0) {
-      const double nn = sqrt(z);
-      r0 /= nn; r1 /= nn; r2 /= nn;
-    }
-    const double ratio = o.mass / (me.mass + o.mass);
-    fx += ((rebounce * r0) * me.mass) * ratio;
-    fy += ((rebounce * r1) * me.mass) * ratio;
-    fz += ((rebounce * r2) * me.mass) * ratio;
-  }
-}
-
-__device__ __forceinline__ bool qualifies(const PosRecord& me, const PosRecord& o, int crash) {
-  const double d0 = me.x - o.x, d1 = me.y - o.y, d2 = me.z - o.z;
-  const double dist = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
-  if (!(dist < 3.0)) return false;  // nanoflann RadiusResultSet(3.0) on the squared distance
-  const double crit_ij = ((me.arm_length + me.prop_radius) + o.arm_length) + o.prop_radius;
-  const double crit_ji = ((o.arm_length + o.prop_radius) + me.arm_length) + me.prop_radius;
-  return dist < crit_ij || (crash && dist < crit_ji);
-}
+// predicate and force expression: collide_device.inc (shared with the fused evaluation inside the step kernels)
+#define apply_partner mrs_apply_partner
+#define qualifies mrs_qualifies
 
 // reference path for one lane: repeated sweeps over the 27 bucket chains, each returning the smallest qualifying partner
 // index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
@@ -226,10 +198,14 @@ __device__ __forceinline__ PosRecord current_record(const SwarmDev& sw, const Po
 }
 
 __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* rec, const uint32_t* nbr, uint32_t cnt, uint32_t j0, int i, int crash,
-                                          double rebounce) {
+                                          double rebounce, Pos4* pos_now) {
   const size_t np = (size_t)sw.npad;  // cnt / j0: the UAV's list length and first row (always a valid index, stale beyond cnt)
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
+  {  // the position the partners of this UAV read in a following fused step + collision launch (step_device.inc *_coll)
+    const Pos4 pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i], 0.0};
+    pos_now[i]    = pp;
+  }
   if (cnt) {
     const PosRecord me = current_record(sw, rec, (uint32_t)i);
     PosRecord       o  = current_record(sw, rec, j0);  // independent of `me`: one memory round trip for both
@@ -253,7 +229,7 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
 template <bool LISTS>
 __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
                               int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
-                              double rebounce) {
+                              double rebounce, Pos4* pos_now) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (LISTS) {
     // issued before the control words are looked at: on a list tick (the common case) these are the first links of the
@@ -273,7 +249,7 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
       for (uint32_t t = (uint32_t)i; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
     }
     if (!rebuild) {  // wave-uniform: nobody has left its skin since the lists were built — this kernel IS the collision tick
-      if (i < sw.n) list_tick(sw, rec, nbr, cnt, j0, i, crash, rebounce);
+      if (i < sw.n) list_tick(sw, rec, nbr, cnt, j0, i, crash, rebounce, pos_now);
       return;
     }
   }
@@ -287,6 +263,10 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   r.arm_length  = P.arm_length;
   r.prop_radius = P.prop_radius;
   rec[i] = r;
+  if (LISTS) {
+    const Pos4 pp = {r.x, r.y, r.z, 0.0};
+    pos_now[i]    = pp;
+  }
   insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
@@ -644,11 +624,22 @@ struct CollideWork {
   PosRecord* g_rec_build = nullptr;  // gathered mode: all records as of this rank's last rebuild
   long long  g_cap = 0;
   bool       g_lists_live = false;
+  // fused step + collision evaluation (step_device.inc *_coll): double-buffered positions, control words, pinned host mirror
+  Pos4*     P[2]  = {nullptr, nullptr};
+  int       pcur  = 0;        // P[pcur] holds the positions after the most recent step (when the host says they are valid)
+  long long p_cap = 0;
+  uint32_t* fctl  = nullptr;  // CTL_WORDS device words
+  uint32_t* hostw = nullptr;  // CTL_WORDS pinned host words (stall, progress mirrored by the kernels)
 };
 
 static void free_work(CollideWork* w) {
   (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
+  (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->fctl);
+  if (w->hostw) (void)hipHostFree(w->hostw);
+  w->P[0] = w->P[1] = nullptr;
+  w->p_cap = 0;
+  w->fctl = w->hostw = nullptr;
   w->g_rec_build = nullptr;
   w->g_cap = 0;
   w->g_lists_live = false;
@@ -707,6 +698,25 @@ static hipError_t ensure_tables(CollideWork* w, long long n_total, hipStream_t s
   return hipSuccess;
 }
 
+// buffers of the fused step + collision evaluation for n local UAVs
+static hipError_t ensure_fused(CollideWork* w, long long n, hipStream_t st) {
+  if (!w->fctl) {
+    CK(hipMalloc(&w->fctl, sizeof(uint32_t) * CTL_WORDS));
+    CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_WORDS, st));
+    CK(hipHostMalloc(&w->hostw, sizeof(uint32_t) * CTL_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    for (int k = 0; k < CTL_WORDS; k++) w->hostw[k] = 0u;
+  }
+  if (n > w->p_cap) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->P[0]); (void)hipFree(w->P[1]);
+    CK(hipMalloc(&w->P[0], sizeof(Pos4) * (size_t)n));
+    CK(hipMalloc(&w->P[1], sizeof(Pos4) * (size_t)n));
+    w->p_cap = n;
+    w->pcur  = 0;
+  }
+  return hipSuccess;
+}
+
 // Plain search every tick over ready (gathered) records — the multi-GPU path, and single-GPU ticks with lists switched off
 // (rec_is_local_scratch: `rec` is this swarm's own, not yet packed, record buffer; pack and insert are then fused).
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
@@ -723,7 +733,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   w->cur ^= 1;
   if (rec_is_local_scratch)
     hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0,
-                       nullptr, 0u, nullptr, nullptr, 0, 0.0);
+                       nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr);
   else
     hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
   hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
@@ -763,6 +773,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
     CK(hipMemsetAsync(w->ctl, 0, sizeof(uint32_t) * 8, st));
     w->fcur = 0;
   }
+  CK(ensure_fused(w, w->cap_n, st));
   if (!w->lists_live) {  // first list tick, or plain-search ticks came in between: start from empty tables and flags
     CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * (size_t)w->cap_T, st));
     CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * (size_t)w->cap_T, st));
@@ -776,7 +787,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
   hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur]);
   hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
@@ -830,4 +841,40 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   w->g_lists_live = true;
   w->lists_live   = false;  // the local-mode skin hook of the step kernel is off
   return hipGetLastError();
+}
+
+// ---- fused step + collision evaluation: what the *_coll step kernels need (single-GPU lists) ----
+// Fills `cd` for the launch with tick index `tau`; the caller launches the kernel and then calls mrs_collide_fused_advance.
+extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd) {
+  if (!w || !w->lists_live || !w->fctl || !w->P[0]) return hipErrorInvalidValue;
+  memset(cd, 0, sizeof *cd);
+  cd->nbr      = w->nbr;
+  cd->nbr_cnt  = w->nbr_cnt;
+  cd->rec      = w->rec_build;
+  cd->p_in     = w->P[w->pcur];
+  cd->p_out    = w->P[w->pcur ^ 1];
+  cd->ctl      = w->fctl;
+  cd->hostw    = w->hostw;
+  cd->rebounce = rebounce;
+  cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  cd->tau      = tau;
+  cd->n        = sw->n;
+  cd->eval     = eval;
+  cd->crash    = crash;
+  cd->world    = 1;
+  cd->block    = 0;
+  return hipSuccess;
+}
+extern "C" void mrs_collide_fused_advance(CollideWork* w) { w->pcur ^= 1; }
+
+// pinned host mirror of the stall / progress words (read without synchronising: the kernels store them with system scope)
+extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w) { return w ? w->hostw : nullptr; }
+
+// forget a stall (the host has synchronised the stream and is about to repeat the search)
+extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st) {
+  if (!w || !w->fctl) return hipSuccess;
+  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * 2, st));
+  w->hostw[CTL_STALL]    = 0u;
+  w->hostw[CTL_PROGRESS] = 0u;
+  return hipSuccess;
 }

@@ -39,6 +39,12 @@ extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** re
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void mrs_collide_free(CollideWork* w);
+extern "C" hipError_t mrs_launch_step_coll_literal(SwarmDev sw, CollDev cd, double dt, int variant, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double dt, int variant, hipStream_t st);
+extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
+extern "C" void mrs_collide_fused_advance(CollideWork* w);
+extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
+extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count, hipStream_t st);
@@ -282,6 +288,22 @@ struct mrs_swarm {
   bool         use_lists = true;   // single-GPU collision ticks reuse neighbour lists between rebuilds (tuning: MRS_NEIGHBOUR_LISTS=0)
   bool         nbr_dirty = true;   // the host wrote positions or airframe constants since the last collision tick
   int64_t      collision_ticks = 0;
+  // Lazily evaluated collision ticks (single-GPU neighbour lists).  handleCollisions is not launched when it is called: it is
+  // evaluated by the NEXT makeStep launch, whose prologue forms the forces from the neighbour lists (step_device.inc *_coll), or
+  // by settle() when the host looks at the swarm first.  `log` holds the launches the device has not confirmed yet: when a UAV
+  // leaves its skin during step T the launches after T turn into no-ops, and the host repeats the search and replays them.
+  struct Collide { bool on = false; int enabled = 0, crash = 0; double rebounce = 0.0; };
+  struct TickRec { double dt; Collide eval; };  // one fused launch: the collision tick it evaluates first, then makeStep(dt)
+  Collide              pend;                        // requested after the most recent step, not evaluated yet
+  bool                 collide_since_step = false;  // ... or evaluated already: either way the next step keeps the fused form
+  bool                 p_valid = false;             // the position records hold the positions after the most recent step
+  bool                 fk_ok   = false;             // the lists are complete (no UAV over the list capacity) and in local mode
+  unsigned             last_overflow = 0;
+  std::vector<TickRec> log;
+  uint32_t             tau = 0;                     // tick index of the last fused launch since the stream was last drained
+  bool                 use_fused = true;            // tuning: MRS_FUSED_COLLISIONS=0 launches every collision tick on its own
+  int                  fused_lead = 8;              // launches the host may run ahead of the device (MRS_FUSED_LEAD)
+  int64_t              n_stalls = 0, n_noop_launches = 0;
   // profiling
   int  profiling = 0;  // 0 off, 1 one event pair around the whole step_n/tick_n region, 2 one pair per step launch
   std::vector<hipEvent_t> ev;
@@ -319,6 +341,15 @@ static void track_mode(mrs_swarm* s, int first, int count, int mode) {
 #define MRS_LOCK(s)                                           \
   std::unique_lock<std::recursive_mutex> _lk;                 \
   if (s) _lk = std::unique_lock<std::recursive_mutex>(const_cast<mrs_swarm*>(s)->mtx)
+
+static int settle(mrs_swarm* s);
+// entry of every call that reads or writes swarm state: collision ticks still pending on the device side are evaluated first
+#define MRS_ENTER(s)                                          \
+  MRS_LOCK(s);                                                \
+  if (s) {                                                    \
+    int _src = settle(const_cast<mrs_swarm*>(s));             \
+    if (_src) return _src;                                    \
+  }
 
 static int check_range(const mrs_swarm* s, int first, int count) {
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
@@ -601,6 +632,8 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
+  if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
+  if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
   HIPCHK(hipMalloc(&s->dS, sizeof(double) * (size_t)F_COUNT * s->npad));
   HIPCHK(hipMalloc(&s->dF, sizeof(uint32_t) * (size_t)s->npad));
   HIPCHK(hipMalloc(&s->dDiag, sizeof(unsigned long long) * 4));
@@ -653,7 +686,7 @@ int mrs_swarm_size(const mrs_swarm_t* s, int32_t* n) {
 }
 
 int mrs_swarm_set_arith(mrs_swarm_t* s, int32_t arith) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || (arith != MRS_ARITH_LITERAL && arith != MRS_ARITH_FAST)) return fail(MRS_ERR_ARG, "bad arith");
   s->arith = arith;
   return MRS_OK;
@@ -669,13 +702,16 @@ int mrs_swarm_stream(const mrs_swarm_t* s, void** stream) {
 int mrs_swarm_synchronize(mrs_swarm_t* s) {
   MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  HIPCHK(hipSetDevice(s->device));
+  int rc = settle(s);  // ticks queued as no-ops behind a stale-list tick are replayed, the last collision tick is evaluated
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(s->stream));
   return MRS_OK;
 }
 
 int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params, const double* pos,
                         const double* heading) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -706,7 +742,7 @@ int mrs_swarm_construct(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_
 }
 
 int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_model_params_t* params) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!params || params->n_motors < 1 || params->n_motors > MRS_MAX_MOTORS) return fail(MRS_ERR_ARG, "bad params");
@@ -723,7 +759,7 @@ int mrs_swarm_set_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs
 }
 
 int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, uav, 1);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -737,34 +773,34 @@ int mrs_swarm_get_params(mrs_swarm_t* s, int32_t uav, mrs_model_params_t* out) {
 }
 
 int mrs_swarm_set_mixer_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_mixer_params_t* p) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   const mrs_mixer_params_t v{p->desaturation ? 1 : 0, 0};
   return set_controller_params(s, first, count, -1, [&](TypeKey& k) { k.mixer = v; });
 }
 int mrs_swarm_set_position_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_position_params_t* p) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 0, [&](TypeKey& k) { k.pos = *p; });
 }
 int mrs_swarm_set_velocity_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_velocity_params_t* p) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 6, [&](TypeKey& k) { k.vel = *p; });
 }
 int mrs_swarm_set_attitude_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_attitude_params_t* p) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 12, [&](TypeKey& k) { k.att = *p; });
 }
 int mrs_swarm_set_rate_params(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_rate_params_t* p) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!p) return fail(MRS_ERR_ARG, "null params");
   return set_controller_params(s, first, count, F_PID + 18, [&](TypeKey& k) { k.rate = *p; });
 }
 
 int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, uav, 1);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -774,7 +810,7 @@ int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
 }
 
 int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (mode < MRS_INPUT_UNKNOWN || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
@@ -801,7 +837,7 @@ int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mo
 }
 
 int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (kind < 0 || kind > 3 || !payload || stride < 4) return fail(MRS_ERR_ARG, "bad feed-forward arguments");
@@ -813,7 +849,7 @@ int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int3
 }
 
 int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const double* force) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!force) return fail(MRS_ERR_ARG, "null force");
@@ -826,7 +862,7 @@ int mrs_swarm_apply_force(mrs_swarm_t* s, int32_t first, int32_t count, const do
 }
 
 int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   HIPCHK(hipSetDevice(s->device));
@@ -834,7 +870,7 @@ int mrs_swarm_crash(mrs_swarm_t* s, int32_t first, int32_t count) {
 }
 
 int mrs_swarm_set_hold(mrs_swarm_t* s, int32_t first, int32_t count, int32_t hold) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -843,7 +879,7 @@ int mrs_swarm_set_hold(mrs_swarm_t* s, int32_t first, int32_t count, int32_t hol
 }
 
 int mrs_swarm_has_crashed(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -920,6 +956,10 @@ static int begin_profile(mrs_swarm* s) {
 }
 
 static int finish_profile(mrs_swarm* s) {
+  if (s->profiling) {  // the timed region ends when every tick of it has really run (replays and the last collision tick included)
+    int rc = settle(s);
+    if (rc) return rc;
+  }
   if (s->profiling == 1) {
     HIPCHK(hipEventRecord(s->ev[1], s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -943,6 +983,149 @@ static int finish_profile(mrs_swarm* s) {
   return MRS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// lazily evaluated collision ticks (see the `pend` / `log` members of mrs_swarm)
+// ------------------------------------------------------------------------------------------------
+// handleCollisions launched on its own: pack + insert / list evaluation, then the query (collide.hip) — the device decides
+// whether the search has to be repeated, unless `force` says so
+static int collide_now(mrs_swarm* s, const mrs_swarm::Collide& c, bool force) {
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
+  if (rc) return rc;
+  HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, c.crash, c.rebounce, (force || s->nbr_dirty) ? 1 : 0, s->stream));
+  s->nbr_dirty = false;
+  // the host must know whether the lists are complete before a step kernel may evaluate a tick from them
+  unsigned w[8];
+  HIPCHK(mrs_collide_debug_words(s->cwork, s->stream, w));  // (synchronises the stream)
+  s->fk_ok         = w[6] == s->last_overflow;  // no UAV over the list capacity in this pass
+  s->last_overflow = w[6];
+  s->p_valid       = true;  // the pass refreshed the position records
+  return MRS_OK;
+}
+
+static bool fused_usable(const mrs_swarm* s) {
+  return s->use_lists && s->use_fused && s->fk_ok && s->p_valid && !s->nbr_dirty && !s->blocks_dirty && !s->types_dirty && s->cwork != nullptr;
+}
+
+// one fused launch: evaluate collision tick `e.eval` (if any) from the lists, then makeStep(e.dt)
+static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
+  const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+  // do not run further ahead of the device than a few launches: when the lists go stale at tick T everything queued behind T is wasted
+  for (long spins = 0; hw && (int)(s->tau - hw[CTL_PROGRESS]) > s->fused_lead && hw[CTL_STALL] == 0u && spins < 200000000L; spins++)
+    __builtin_ia32_pause();
+  if (e.dt != s->table_dt) {  // (a replayed tick of another dt: the motor-filter constants of the type table follow)
+    int rc = upload_types(s, e.dt);
+    if (rc) return rc;
+  }
+  CollDev cd;
+  SwarmDev v = s->view();
+  HIPCHK(mrs_collide_fused_dev(&v, s->cwork, s->tau + 1, e.eval.on ? 1 : 0, e.eval.crash, e.eval.rebounce, &cd));
+  const int variant = s->n_cascade > 0 ? 0 : 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  s->region_launches++;
+  if (s->profiling == 2) {
+    while ((int)s->ev.size() < s->ev_used + 2) {
+      hipEvent_t ev;
+      HIPCHK(hipEventCreate(&ev));
+      s->ev.push_back(ev);
+    }
+    e0 = s->ev[(size_t)s->ev_used];
+    e1 = s->ev[(size_t)s->ev_used + 1];
+    s->ev_used += 2;
+    HIPCHK(hipEventRecord(e0, s->stream));
+  }
+  if (s->arith == MRS_ARITH_FAST)
+    HIPCHK(mrs_launch_step_coll_fast(v, cd, e.dt, variant, s->stream));
+  else
+    HIPCHK(mrs_launch_step_coll_literal(v, cd, e.dt, variant, s->stream));
+  if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
+  mrs_collide_fused_advance(s->cwork);
+  s->tau++;
+  s->log.push_back(e);
+  if (e.eval.on) s->fext_active = true;
+  return MRS_OK;
+}
+
+// Wait for the device and make good for launches that turned into no-ops: if the lists went stale during step T (a UAV left its
+// skin), repeat the search on the state after step T — which also evaluates the collision tick that followed step T — and issue
+// the ticks after T again.  Returns with an empty log.
+static int drain(mrs_swarm* s) {
+  if (s->log.empty()) return MRS_OK;
+  const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+  for (;;) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const unsigned T = hw ? hw[CTL_STALL] : 0u;
+    if (T == 0u || T > s->log.size()) {
+      s->log.clear();
+      s->tau = 0;
+      if (T) return fail(MRS_ERR_HIP, "collision lists: stall index beyond the launch log");
+      HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));  // (progress word back to 0 with tau)
+      return MRS_OK;
+    }
+    s->n_stalls++;
+    s->n_noop_launches += (int64_t)s->log.size() - T;
+    std::vector<mrs_swarm::TickRec> tail(s->log.begin() + T, s->log.end());
+    s->log.clear();
+    s->tau = 0;
+    HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));
+    // the collision tick that followed step T: the first replayed launch was going to evaluate it, or it is the pending one
+    mrs_swarm::Collide& c = tail.empty() ? s->pend : tail[0].eval;
+    if (c.on) {
+      int rc = collide_now(s, c, /*force=*/true);
+      if (rc) return rc;
+      c.on = false;
+    } else {
+      s->fk_ok = false;  // nobody needs the lists right now: the next collision tick starts with a search
+      s->nbr_dirty = true;
+    }
+    for (const auto& e : tail) {
+      int rc;
+      if (fused_usable(s)) {
+        if ((rc = launch_fused(s, e))) return rc;
+      } else {  // (lists incomplete: dense neighbourhoods) every tick on its own
+        if (e.eval.on && (rc = collide_now(s, e.eval, false))) return rc;
+        s->p_valid = false;
+        s->region_launches++;
+        if ((rc = launch_part(s, e.dt, 1, 0, (s->n + 63) / 64, 1, s->stream))) return rc;
+      }
+    }
+    if (s->log.empty()) return MRS_OK;
+  }
+}
+
+// everything the caller asked for so far has happened on the device (asynchronously at most the plain launches)
+static int settle(mrs_swarm* s) {
+  if (s->log.empty() && !s->pend.on) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = drain(s);
+  if (rc) return rc;
+  if (s->pend.on) {
+    const mrs_swarm::Collide c = s->pend;
+    s->pend.on = false;
+    if ((rc = collide_now(s, c, false))) return rc;
+  }
+  return MRS_OK;
+}
+
+// one makeStep of every UAV; the collision tick requested since the previous step (if any) is evaluated by the same launch
+static int step_one(mrs_swarm* s, double dt) {
+  int rc;
+  if (s->collide_since_step && s->use_lists && s->use_fused) {
+    const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+    if (hw && hw[CTL_STALL] != 0u && (rc = drain(s))) return rc;  // seen without synchronising: stop feeding no-ops
+    if (s->pend.on && !fused_usable(s) && (rc = settle(s))) return rc;  // first tick / after host writes: the pass on its own
+    if (fused_usable(s)) {
+      mrs_swarm::TickRec e{dt, s->pend};
+      s->pend.on            = false;
+      s->collide_since_step = false;
+      return launch_fused(s, e);
+    }
+  }
+  if ((rc = settle(s))) return rc;
+  s->collide_since_step = false;
+  s->p_valid            = false;  // a plain step kernel does not refresh the position records
+  return launch_step(s, dt, 1);
+}
+
 int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substeps_per_launch) {
   MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
@@ -952,17 +1135,29 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   int rc = upload_types(s, dt);
   if (rc) return rc;
   if ((rc = begin_profile(s))) return rc;
-  // enough launches to overlap, enough blocks for two useful halves, and no per-launch events to keep in order
-  static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
-  const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
-  if (split && (rc = fork_streams(s))) return rc;
-  int left = n_steps;
-  while (left > 0) {
-    const int sub = left < substeps_per_launch ? left : substeps_per_launch;
-    if ((rc = split ? launch_step_split(s, dt, sub) : launch_step(s, dt, sub))) return rc;
-    left -= sub;
+  if (s->collide_since_step && substeps_per_launch == 1) {  // the first step of the run may carry a collision tick
+    if ((rc = step_one(s, dt))) return rc;
+    n_steps--;
   }
-  if (split && (rc = join_streams(s))) return rc;
+  if (n_steps > 0) {
+    if ((rc = settle(s))) return rc;
+    s->p_valid = false;
+    // enough launches to overlap, enough blocks for two useful halves, and no per-launch events to keep in order
+    static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
+    const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
+    if (split && (rc = fork_streams(s))) return rc;
+    int left = n_steps;
+    while (left > 0 && rc == MRS_OK) {
+      const int sub = left < substeps_per_launch ? left : substeps_per_launch;
+      rc = split ? launch_step_split(s, dt, sub) : launch_step(s, dt, sub);
+      left -= sub;
+    }
+    if (split) {  // also on a failed launch: nothing else may touch the state before the second stream has been joined
+      const int rcj = join_streams(s);
+      if (rc == MRS_OK) rc = rcj;
+    }
+    if (rc) return rc;
+  }
   return finish_profile(s);
 }
 
@@ -970,7 +1165,7 @@ int mrs_swarm_step(mrs_swarm_t* s, double dt) {
   MRS_LOCK(s); return mrs_swarm_step_n(s, dt, 1, 1); }
 
 int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
@@ -983,7 +1178,7 @@ int mrs_swarm_pack_positions(mrs_swarm_t* s, void** dev_ptr, int64_t* n_bytes) {
 }
 
 int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !dev_dst) return fail(MRS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
@@ -994,7 +1189,7 @@ int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst) {
 
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset, int32_t enabled,
                                          int32_t crash, double rebounce) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
   if (!dev_records || n_total < s->n || my_offset < 0 || my_offset + s->n > n_total) return fail(MRS_ERR_ARG, "bad gathered-record arguments");
@@ -1016,15 +1211,20 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
   if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
   if (s->n == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
-  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
-  if (rc) return rc;
-  s->fext_active = true;
+  int rc;
   s->collision_ticks++;
   if (s->use_lists) {
-    HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, crash, rebounce, s->nbr_dirty ? 1 : 0, s->stream));
-    s->nbr_dirty = false;
-    return MRS_OK;
+    // two collision ticks without a step in between: the earlier one is evaluated now (its crash flags stay, its forces are overwritten)
+    if (s->pend.on && (rc = settle(s))) return rc;
+    s->fext_active        = true;
+    s->pend               = mrs_swarm::Collide{true, enabled, crash, rebounce};
+    s->collide_since_step = true;
+    if (!s->use_fused) return settle(s);
+    return MRS_OK;  // evaluated by the next step launch, or by settle() when the host looks at the swarm first
   }
+  if ((rc = settle(s))) return rc;
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  s->fext_active = true;
   if (!s->dRec) HIPCHK(hipMalloc(&s->dRec, sizeof(PosRecord) * (size_t)s->npad));
   HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->dRec, s->n, 0, crash, rebounce, /*rec_is_local_scratch=*/1, s->stream));
   return MRS_OK;
@@ -1073,7 +1273,7 @@ int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128) {
 }
 
 int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !id128) return fail(MRS_ERR_ARG, "null argument");
   if (world < 1 || rank < 0 || rank >= world || n_total < s->n) return fail(MRS_ERR_ARG, "bad communicator shape");
   const int64_t base = n_total / world, rem = n_total % world;
@@ -1097,7 +1297,7 @@ int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world,
 }
 
 int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!s->rccl_comm) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
@@ -1111,7 +1311,7 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
 }
 
 int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
   memset(out, 0, sizeof *out);
   if (!s->rccl_comm) return MRS_OK;
@@ -1132,7 +1332,7 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
 // timerMain on every rank of a sharded swarm: step, pack, ONE all-gather of the 48-B records on the swarm's own stream, collision
 // pass against the gathered records — no host synchronisation and no other stream inside the loop
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!s->rccl_comm) return fail(MRS_ERR_ARG, "mrs_swarm_comm_init has not been called");
   if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
@@ -1171,7 +1371,7 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
   if (rc) return rc;
   if ((rc = begin_profile(s))) return rc;
   for (int k = 0; k < n_ticks; k++) {
-    if ((rc = launch_step(s, dt, 1))) return rc;
+    if ((rc = step_one(s, dt))) return rc;
     if ((rc = mrs_swarm_handle_collisions(s, enabled, crash, rebounce))) return rc;
   }
   return finish_profile(s);
@@ -1180,7 +1380,7 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
 // ---- state access ----
 int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x, double* v, double* v_prev, double* R, double* omega,
                         double* motor_rpm) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -1206,7 +1406,7 @@ int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x,
 
 int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
                         const double* omega, const double* motor_rpm) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -1245,7 +1445,7 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
 }
 
 int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!imu) return fail(MRS_ERR_ARG, "null out");
@@ -1256,7 +1456,7 @@ int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu)
 }
 
 int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, double* force) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!force) return fail(MRS_ERR_ARG, "null out");
@@ -1267,7 +1467,7 @@ int mrs_swarm_get_external_force(mrs_swarm_t* s, int32_t first, int32_t count, d
 }
 
 int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!pid) return fail(MRS_ERR_ARG, "null out");
@@ -1278,7 +1478,7 @@ int mrs_swarm_get_pid(mrs_swarm_t* s, int32_t first, int32_t count, double* pid)
 }
 
 int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
   unsigned long long d[4];
@@ -1292,7 +1492,7 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
 }
 
 int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -1302,7 +1502,7 @@ int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
 }
 
 int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   return modify_params(s, first, count, [&](mrs_model_params_t& p) {  // src/uav_system_ros.cpp:1036-1047
     const double original_mass = p.mass;
     p.mass = mass;
@@ -1312,7 +1512,7 @@ int mrs_swarm_set_mass(mrs_swarm_t* s, int32_t first, int32_t count, double mass
 }
 
 int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double ground_z) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   return modify_params(s, first, count, [&](mrs_model_params_t& p) { p.ground_z = ground_z; });  // :1063-1073
 }
 
@@ -1335,7 +1535,7 @@ static int fetch_outputs(mrs_swarm* s, int32_t first, int32_t count) {
 }
 
 int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_output_t* out) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!out) return fail(MRS_ERR_ARG, "null out");
@@ -1346,7 +1546,7 @@ int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_
 }
 
 int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_uav_output_t** view) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (!view) return fail(MRS_ERR_ARG, "null view");
@@ -1358,7 +1558,7 @@ int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, con
 }
 
 int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, double** rows) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !rows) return fail(MRS_ERR_ARG, "null argument");
   if (count < 0 || count > s->n || stride < 1 || stride > 16) return fail(MRS_ERR_ARG, "bad staging shape");
   HIPCHK(hipSetDevice(s->device));
@@ -1378,7 +1578,7 @@ int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, doubl
 }
 
 int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, int32_t stride) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (mode < MRS_ACTUATOR_CMD || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
@@ -1401,7 +1601,7 @@ int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t
 }
 
 int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   HIPCHK(hipSetDevice(s->device));
   unsigned rb = 0;
@@ -1438,7 +1638,7 @@ int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int
 }
 
 int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8) {
-  MRS_LOCK(s);
+  MRS_ENTER(s);
   if (!s || !out8) return fail(MRS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(mrs_collide_debug_words(s->cwork, s->stream, out8));

@@ -89,3 +89,45 @@ struct PosRecord {
   double x, y, z;
   double mass, arm_length, prop_radius;
 };
+
+// ---- fused step + collision evaluation (step_device.inc *_coll kernels; buffers owned by collide.hip) ----
+// A collision tick between two neighbour searches is evaluated by the NEXT step kernel: its prologue reads the positions of
+// the listed partners as they were after the previous step, forms the force / crash flag handleCollisions would have
+// latched (src/multirotor_simulator.cpp:321-358) and the step consumes it from registers.  Positions are double-buffered in
+// their own 32-B records so that the partners' values do not change under a running launch.
+struct Pos4 {
+  double x, y, z, w;  // w: header records carry flags here, position records 0
+};
+struct PartnerConst {
+  double mass, arm_length, prop_radius, _pad;
+};
+#define MRS_NBR_FOREIGN 0x80000000u  // neighbour-list entry: index into the gathered export buffer instead of a local UAV index
+#define MRS_NO_SLOT     0xFFFFFFFFu
+
+// control words of the list state machine (device copy `ctl`, mirrored to pinned host memory `hostw` for the first two)
+enum {
+  CTL_STALL = 0,     // 0, or the tick index of the launch after which the lists stopped being usable (every later launch is a no-op)
+  CTL_PROGRESS = 1,  // tick index of the last launch that started
+  CTL_OVERFLOW = 2,  // UAVs with more than LIST_CAP listed neighbours at the last search
+  CTL_BADSLOT = 3,   // export-set translation: foreign neighbours that their owner does not export (must stay 0: the relation is symmetric)
+  CTL_EXPORTS = 4,   // export-set search: number of own UAVs that some other rank lists
+  CTL_WORDS = 8
+};
+
+struct CollDev {
+  const uint32_t*     nbr;      // [LIST_CAP][n]: row k, UAV i at nbr[k * n + i]; ascending partner order
+  const uint32_t*     nbr_cnt;  // [n]
+  const PosRecord*    rec;      // [n] records of the last search: skin-test reference position + airframe constants of local partners
+  const Pos4*         p_in;     // [n] positions after the previous step
+  Pos4*               p_out;    // [n] positions after this step
+  uint32_t*           ctl;      // CTL_WORDS control words
+  volatile uint32_t*  hostw;    // pinned host mirror of ctl[CTL_STALL], ctl[CTL_PROGRESS]
+  // export-set exchange (world > 1): every rank's block of the gathered buffer is [header][cap] Pos4 records
+  const Pos4*         g_pos;    // [world * (1 + cap)] gathered export positions of the previous tick
+  const PartnerConst* g_const;  // [world * (1 + cap)] airframe constants of the exported UAVs (fixed between searches)
+  Pos4*               send;     // [1 + cap] this rank's block of the next all-gather
+  const uint32_t*     exp_slot; // [n] export slot of every own UAV (MRS_NO_SLOT: nobody else lists it)
+  double              rebounce, lim2;
+  uint32_t            tau;      // tick index of this launch (1, 2, ... since the host last drained the stream)
+  int32_t             n, eval, crash, world, block;  // block = 1 + cap
+};

@@ -85,6 +85,8 @@ def test_config5_one_million_uavs_eight_virtual_shards(mrs, oracle):
             g.synchronize()
         for r, (g, lo, hi) in enumerate(shards):
             g.handle_collisions_gathered(recv.data_ptr(), WORLD * n_max, r * n_max, True, False, 100.0)
+        for g, _, _ in shards:
+            g.synchronize()  # every shard has read the gathered buffer before anyone's next pack overwrites its block
     sh = {k: np.concatenate([g.get_state()[k] for g, _, _ in shards]) for k in ("x", "v", "R", "omega", "motor_rpm")}
     sh["f"] = np.concatenate([g.get_external_force() for g, _, _ in shards])
     sh["pid"] = np.concatenate([g.get_pid() for g, _, _ in shards])
