@@ -43,6 +43,9 @@ enum {
 /* the four std::optional feed-forward slots — uav_system.hpp:112-115 */
 enum { MRS_FF_VELOCITY_HDG_RATE = 0, MRS_FF_VELOCITY_HDG, MRS_FF_ACCELERATION_HDG_RATE, MRS_FF_ACCELERATION_HDG };
 
+/* multi-GPU collision exchange (mrs_swarm_set_exchange) */
+enum { MRS_EXCHANGE_NONE = 0, MRS_EXCHANGE_FULL_GATHER = 1, MRS_EXCHANGE_EXPORT_SETS = 2 };
+
 /* arithmetic flavour of the step kernel */
 enum {
   MRS_ARITH_LITERAL = 0, /* reference operation order, no FMA contraction: bit-comparable with a scalar CPU restatement */
@@ -209,20 +212,41 @@ int mrs_swarm_pack_positions_to(mrs_swarm_t* s, void* dev_dst);
 int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records, int64_t n_total, int64_t my_offset,
                                          int32_t enabled, int32_t crash, double rebounce);
 
-/* The same exchange done by the library itself, for hosts that do not want to drive RCCL: the all-gather is issued on the
- * swarm's own stream between the step kernel and the collision pass, so a whole run of ticks is one asynchronous call.
- * RCCL is bound at run time from `librccl_path` (NULL = "librccl.so" from the loader path; a process that already holds a HIP
- * runtime — PyTorch-ROCm ships its own — must name the librccl.so that belongs to THAT runtime).
- *   mrs_rccl_unique_id   : rank 0 creates the 128-byte id and hands it to the other ranks by any host channel
- *   mrs_swarm_comm_init  : collective; shards are the static contiguous index ranges of n_total UAVs over `world` ranks
- *                          (sizes differ by at most one, larger shards first); this swarm must hold the shard of `rank`
+/* The same exchange done by the library itself, for hosts that do not want to drive the collective: it is issued on the swarm's own
+ * stream between the kernels, so a whole run of ticks is one call.  Two exchanges exist (mrs_swarm_set_exchange):
+ *   MRS_EXCHANGE_EXPORT_SETS (default) — SURVEY 8e v2, "all-gather of boundary-UAV positions": a tick that repeats the neighbour
+ *       search gathers all 48-B records; every tick until the next search gathers only the UAVs some other rank lists (32 B each,
+ *       padded to the largest export set), and the collision tick is evaluated by the next step kernel (as on one GPU);
+ *   MRS_EXCHANGE_FULL_GATHER — all 48-B records on every tick.
+ * Results are identical.  Shards are equal-count index ranges of the caller's (spatially sorted, see mrs_slab_partition) order.
+ * Collective backends:
+ *   RCCL, bound at run time from `librccl_path` (NULL = "librccl.so" from the loader path; a process that already holds a HIP
+ *       runtime — PyTorch-ROCm ships its own — must name the librccl.so that belongs to THAT runtime):
+ *         mrs_rccl_unique_id   : rank 0 creates the 128-byte id and hands it to the other ranks by any host channel
+ *         mrs_swarm_comm_init  : collective; this swarm must hold the shard of `rank` (n_total / world UAVs, the first
+ *                                n_total % world ranks one more)
+ *   a caller-supplied all-gather (mrs_swarm_comm_init_custom): `fn` must enqueue, on `stream`, the all-gather of `bytes_per_rank`
+ *       bytes from `send` into `recv` (rank-major) and return 0; every rank calls it the same number of times in the same order
+ *   an in-process group (mrs_loopback_group_*): `world` swarms of ONE process, each driven by its own host thread, on one device
+ *       ("virtual shards", what the tests use on the one-GPU box) or on several devices of a node without RCCL
  *   mrs_swarm_tick_sharded_n : n_ticks of timerMain on every rank — makeStep, then handleCollisions over ALL n_total UAVs
- *                          (src/multirotor_simulator.cpp:211-217, 295-359); collective, asynchronous
+ *                          (src/multirotor_simulator.cpp:211-217, 295-359); collective; returns with every tick evaluated
  *   mrs_swarm_comm_destroy   : collective */
+typedef int (*mrs_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes_per_rank, void* stream);
+typedef struct mrs_loopback_group mrs_loopback_group_t;
 int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128);
 int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total);
+int mrs_swarm_comm_init_custom(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, mrs_allgather_fn fn, void* user);
+int mrs_loopback_group_create(int32_t world, mrs_loopback_group_t** out);
+int mrs_loopback_group_destroy(mrs_loopback_group_t* g);
+int mrs_swarm_comm_init_loopback(mrs_swarm_t* s, mrs_loopback_group_t* g, int32_t rank, int64_t n_total);
+int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange);
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
 int mrs_swarm_comm_destroy(mrs_swarm_t* s);
+/* Spatially coherent shards for a swarm addressed by a fixed public index (the reference's uavs_[i]): UAVs sorted by x and cut into
+ * `world` equal-count slabs (n_total / world each, the first n_total % world one more).  order[k] = public index of the UAV at
+ * position k of the sorted order (rank r holds order[lo_r .. hi_r)); host only. */
+int mrs_slab_partition(const double* pos_xyz, int64_t n_total, int32_t world, int64_t* order);
 /* what the communicator of this swarm looks like: ranks as mrs_swarm_comm_init was told and as RCCL itself counts them
  * (ncclCommCount), the exchange in use and the bytes every rank contributes to the per-tick collective */
 typedef struct {
@@ -233,8 +257,8 @@ typedef struct {
   int64_t bytes_per_tick;   /* bytes this rank sends into the collision collective of an ordinary tick */
   int64_t bytes_per_rebuild; /* bytes it sends on a tick that repeats the neighbour search (export-set exchange only) */
   int64_t export_count, export_capacity; /* export-set exchange: own UAVs some other rank lists / slots of the padded collective */
+  int64_t ticks, searches, noop_ticks;   /* sharded ticks so far, how many repeated the search, launches replayed after a stale-list tick */
 } mrs_comm_info_t;
-enum { MRS_EXCHANGE_NONE = 0, MRS_EXCHANGE_FULL_GATHER = 1, MRS_EXCHANGE_EXPORT_SETS = 2 };
 int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out);
 
 /* collision-pass statistics of mrs_swarm_handle_collisions / mrs_swarm_tick_n: ticks that ran the pass, and how many of them had to

@@ -630,11 +630,22 @@ struct CollideWork {
   long long p_cap = 0;
   uint32_t* fctl  = nullptr;  // CTL_WORDS device words
   uint32_t* hostw = nullptr;  // CTL_WORDS pinned host words (stall, progress mirrored by the kernels)
+  // export-set exchange (multi-GPU ticks between searches): own UAVs listed by another rank, their slots in the padded collective
+  uint32_t*     exp_slot = nullptr;   // [n_local]
+  long long     exp_slot_cap = 0;
+  Pos4*         x_send = nullptr;     // [1 + x_cap]: header + exported positions of this rank
+  Pos4*         x_recv = nullptr;     // [world][1 + x_cap]
+  PartnerConst* x_const = nullptr;    // [world][1 + x_cap]
+  long long     x_cap = 0;            // export slots per rank in the collective
+  int           x_world = 0;
 };
 
 static void free_work(CollideWork* w) {
   (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
+  (void)hipFree(w->exp_slot); (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
+  w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
+  w->exp_slot_cap = w->x_cap = 0;
   (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->fctl);
   if (w->hostw) (void)hipHostFree(w->hostw);
   w->P[0] = w->P[1] = nullptr;
@@ -798,7 +809,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
 
 // Multi-GPU tick with neighbour lists: `rec` = the gathered current records of all ranks (NaN padding included).
 extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
-                                                     int crash, double rebounce, hipStream_t st) {
+                                                     int crash, double rebounce, int force_rebuild, hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
   CK(ensure_tables(w, n_total, st));
@@ -824,7 +835,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
     CK(hipMemsetAsync(w->g_rec_build, 0xFF, sizeof(PosRecord) * (size_t)w->g_cap, st));  // NaN records
     w->fcur = 0;
   }
-  const int      force = w->g_lists_live ? 0 : 1;
+  const int      force = (w->g_lists_live && !force_rebuild) ? 0 : 1;
   const uint32_t T = w->cap_T, mask = T - 1;
   const int      tid  = w->cur;
   uint2*         head = w->head[tid];
@@ -877,4 +888,216 @@ extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st) {
   w->hostw[CTL_STALL]    = 0u;
   w->hostw[CTL_PROGRESS] = 0u;
   return hipSuccess;
+}
+
+// ================================================================================================================================
+// Export-set exchange (multi-GPU): between two searches a rank only needs the positions of the FOREIGN UAVs its neighbour lists
+// name, and only has to publish the own UAVs some other rank lists.  Those two sets mirror each other — "j within the list radius
+// of i" is decided by the same squared distance on both sides, from the same gathered records — so a rank finds its export set in
+// its own lists: own UAV i is exported iff its list holds a foreign UAV.  A search tick (full gather, mrs_collide_run_lists_gathered)
+// is followed by
+//   k_export_mark      : export slot e_i for every own UAV with a foreign neighbour (any injective numbering will do)
+//   all-gather         : the slot maps of all ranks (4 B per UAV), headed by each rank's count
+//   k_export_translate : list entries (global record slots) -> local UAV index | FOREIGN + slot in the padded export collective;
+//                        airframe constants and search-time positions of the foreign partners are copied next to those slots
+// and every tick until the next search all-gathers 32 B per EXPORTED UAV instead of 48 B per UAV.
+// ================================================================================================================================
+namespace {
+
+__global__ void k_fill_positions(SwarmDev sw, Pos4* pos_now) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sw.n) return;
+  const size_t np = (size_t)sw.npad;
+  const Pos4   pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i], 0.0};
+  pos_now[i]      = pp;
+}
+
+// map: [0] export count of this rank, [1] lanes over the list capacity so far, [2 + i] slot of own UAV i
+__global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot, uint32_t* map,
+                              uint32_t* fctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cnt = nbr_cnt[i];
+  bool           exported = false;
+  for (uint32_t k = 0; k < cnt; k++) {
+    const uint32_t g = nbr[(size_t)k * (size_t)n + (size_t)i];
+    if ((long long)g / n_max != (long long)rank) exported = true;
+  }
+  uint32_t e = MRS_NO_SLOT;
+  if (exported) e = atomicAdd(&fctl[CTL_EXPORTS], 1u);
+  exp_slot[i] = e;
+  map[2 + i]  = e;
+}
+
+__global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint32_t* ctl) {
+  map[0] = fctl[CTL_EXPORTS];
+  map[1] = ctl[6];  // lanes over the list capacity (cumulative, collide.hip k_query)
+}
+
+__global__ void k_export_translate(int n, long long n_max, int rank, long long map_stride, int block, uint32_t* nbr, const uint32_t* nbr_cnt,
+                                   const uint32_t* maps, const PosRecord* rec_all, Pos4* x_recv, PartnerConst* x_const, uint32_t* fctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cnt = nbr_cnt[i];
+  for (uint32_t k = 0; k < cnt; k++) {
+    const size_t    at = (size_t)k * (size_t)n + (size_t)i;
+    const uint32_t  g  = nbr[at];
+    const long long q  = (long long)g / n_max, j = (long long)g - q * n_max;
+    if (q == (long long)rank) {
+      nbr[at] = (uint32_t)j;
+      continue;
+    }
+    const uint32_t e = maps[(size_t)q * (size_t)map_stride + 2 + (size_t)j];
+    if (e == MRS_NO_SLOT || (long long)e + 1 >= (long long)block) {  // cannot happen (symmetry / capacity checked by the host): keep the entry harmless
+      atomicAdd(&fctl[CTL_BADSLOT], 1u);
+      nbr[at] = MRS_NBR_FOREIGN | (uint32_t)(q * block);  // the owner's header record: w = stall word, position (0,0,0) + zero constants
+      continue;
+    }
+    const uint32_t slot = (uint32_t)(q * block + 1 + e);
+    nbr[at] = MRS_NBR_FOREIGN | slot;
+    const PosRecord r = rec_all[g];  // several lanes may write the same slot: same values
+    const Pos4         pp = {r.x, r.y, r.z, 0.0};
+    const PartnerConst cc = {r.mass, r.arm_length, r.prop_radius, 0.0};
+    x_recv[slot]  = pp;
+    x_const[slot] = cc;
+  }
+}
+
+// handleCollisions of the tick after the most recent step, evaluated on its own from the lists (local partners: position records,
+// foreign partners: gathered export buffer — both current): the settle step at the end of a run of sharded ticks
+__global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sw.n) return;
+  const size_t      np = (size_t)sw.npad;
+  const TypeParams& P  = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
+  PosRecord         me;
+  me.x = sw.S[(size_t)(F_X + 0) * np + i];
+  me.y = sw.S[(size_t)(F_X + 1) * np + i];
+  me.z = sw.S[(size_t)(F_X + 2) * np + i];
+  me.mass = P.mass; me.arm_length = P.arm_length; me.prop_radius = P.prop_radius;
+  double f[3];
+  bool   crashed;
+  mrs_list_eval(cd, i, me, cd.nbr_cnt[i], cd.nbr[i], f, crashed);
+  sw.S[(size_t)(F_FEXT + 0) * np + i] = f[0];
+  sw.S[(size_t)(F_FEXT + 1) * np + i] = f[1];
+  sw.S[(size_t)(F_FEXT + 2) * np + i] = f[2];
+  if (crashed) sw.F[i] |= FLAG_CRASHED;
+}
+
+// the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
+// batch of ticks, whose last launch nobody has looked behind yet
+__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, uint32_t* fctl, volatile uint32_t* hostw) {
+  uint32_t stall = fctl[CTL_STALL];
+  for (int q = 0; q < world; q++) {
+    const uint32_t h = (uint32_t)x_recv[(size_t)q * (size_t)block].w;
+    if (h != 0u && (stall == 0u || h < stall)) stall = h;
+  }
+  fctl[CTL_STALL] = stall;
+  __hip_atomic_store(&hostw[CTL_STALL], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+// sizes of the export-set exchange for `world` ranks and `cap` export slots per rank; buffers zeroed (headers!)
+extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, hipStream_t st) {
+  if (!*work) *work = new CollideWork();
+  CollideWork* w = *work;
+  CK(ensure_fused(w, sw.n > 0 ? sw.n : 1, st));
+  if ((long long)sw.n > w->exp_slot_cap) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->exp_slot);
+    CK(hipMalloc(&w->exp_slot, sizeof(uint32_t) * (size_t)(sw.n > 0 ? sw.n : 1)));
+    w->exp_slot_cap = sw.n;
+  }
+  if (cap > w->x_cap || world != w->x_world) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
+    const size_t block = (size_t)cap + 1;
+    CK(hipMalloc(&w->x_send, sizeof(Pos4) * block));
+    CK(hipMalloc(&w->x_recv, sizeof(Pos4) * block * (size_t)world));
+    CK(hipMalloc(&w->x_const, sizeof(PartnerConst) * block * (size_t)world));
+    w->x_cap   = cap;
+    w->x_world = world;
+  }
+  const size_t block = (size_t)w->x_cap + 1;
+  CK(hipMemsetAsync(w->x_send, 0, sizeof(Pos4) * block, st));
+  CK(hipMemsetAsync(w->x_recv, 0, sizeof(Pos4) * block * (size_t)world, st));
+  CK(hipMemsetAsync(w->x_const, 0, sizeof(PartnerConst) * block * (size_t)world, st));
+  return hipSuccess;
+}
+
+extern "C" long long mrs_collide_export_capacity(const CollideWork* w) { return w ? w->x_cap : 0; }
+extern "C" void*     mrs_collide_export_send(const CollideWork* w) { return w ? (void*)w->x_send : nullptr; }
+extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? (void*)w->x_recv : nullptr; }
+
+// after a search over gathered records: mark the export set, write this rank's slot map (2 + n_max words) for the all-gather
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st) {
+  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_WORDS, st));
+  CK(hipMemsetAsync(map_send, 0xFF, sizeof(uint32_t) * (size_t)(n_max + 2), st));  // padding UAVs: no slot
+  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = 0u;
+  if (sw.n > 0) {
+    hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl);
+    hipLaunchKernelGGL(k_fill_positions, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur]);
+  }
+  hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, st, map_send, w->fctl, w->ctl ? w->ctl : w->fctl);  // (a rank without UAVs never searched: word 6 of fctl is 0)
+  return hipGetLastError();
+}
+
+// after the all-gather of the slot maps (and with buffers of sufficient capacity): rewrite the lists, seed the gathered export buffer
+extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, int rank, const uint32_t* maps, const PosRecord* rec_all,
+                                                   hipStream_t st) {
+  if (sw.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, n_max + 2, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
+                     maps, rec_all, w->x_recv, w->x_const, w->fctl);
+  return hipGetLastError();
+}
+
+// CollDev of a sharded fused launch (export-set exchange); rec_own = this rank's records as of the search (gathered buffer + offset)
+extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w, long long my_offset, unsigned tau, int eval, int crash, double rebounce,
+                                             CollDev* cd) {
+  if (!w || !w->fctl || !w->P[0] || !w->x_send || !w->g_rec_build) return hipErrorInvalidValue;
+  memset(cd, 0, sizeof *cd);
+  cd->nbr      = w->nbr;
+  cd->nbr_cnt  = w->nbr_cnt;
+  cd->rec      = w->g_rec_build + my_offset;
+  cd->p_in     = w->P[w->pcur];
+  cd->p_out    = w->P[w->pcur ^ 1];
+  cd->ctl      = w->fctl;
+  cd->hostw    = w->hostw;
+  cd->g_pos    = w->x_recv;
+  cd->g_const  = w->x_const;
+  cd->send     = w->x_send;
+  cd->exp_slot = w->exp_slot;
+  cd->rebounce = rebounce;
+  cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  cd->tau      = tau;
+  cd->n        = sw->n;
+  cd->eval     = eval;
+  cd->crash    = crash;
+  cd->world    = w->x_world;
+  cd->block    = (int)(w->x_cap + 1);
+  return hipSuccess;
+}
+
+extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st) {
+  if (sw.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_list_eval_cd, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->fctl, w->hostw);
+  return hipGetLastError();
+}
+
+// control words of the fused machinery (synchronises the stream)
+extern "C" hipError_t mrs_collide_fused_words(const CollideWork* w, hipStream_t st, unsigned* out8) {
+  for (int k = 0; k < CTL_WORDS; k++) out8[k] = 0;
+  if (!w || !w->fctl) return hipSuccess;
+  CK(hipMemcpyAsync(out8, w->fctl, CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
+extern "C" void mrs_collide_invalidate_gathered(CollideWork* w) {
+  if (w) w->g_lists_live = false;
 }

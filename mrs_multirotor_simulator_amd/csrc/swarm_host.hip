@@ -9,8 +9,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <dlfcn.h>
 #include <string>
 #include <vector>
@@ -34,7 +38,20 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
                                       int crash, double rebounce, int rec_is_local_scratch, hipStream_t st);
 extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st);
 extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
-                                                     int crash, double rebounce, hipStream_t st);
+                                                     int crash, double rebounce, int force_rebuild, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, hipStream_t st);
+extern "C" long long  mrs_collide_export_capacity(const CollideWork* w);
+extern "C" void*      mrs_collide_export_send(const CollideWork* w);
+extern "C" void*      mrs_collide_export_recv(const CollideWork* w);
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, int rank, const uint32_t* maps, const PosRecord* rec_all,
+                                                   hipStream_t st);
+extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w, long long my_offset, unsigned tau, int eval, int crash, double rebounce,
+                                             CollDev* cd);
+extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, hipStream_t st);
+extern "C" hipError_t mrs_collide_fused_words(const CollideWork* w, hipStream_t st, unsigned* out8);
+extern "C" void       mrs_collide_invalidate_gathered(CollideWork* w);
 extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
@@ -257,10 +274,25 @@ struct mrs_swarm {
   bool        split_steps = true;  // tuning: MRS_SPLIT_STREAMS=0
   // native multi-GPU collision exchange (mrs_swarm_comm_init): RCCL all-gather issued on `stream`
   void*      rccl_comm = nullptr;
-  int        comm_world = 0, comm_rank = 0;
+  int        comm_world = 0, comm_rank = 0;   // comm_world > 0: a communicator of some kind is bound
   int64_t    comm_n_total = 0, comm_n_max = 0;
   PosRecord* comm_send = nullptr;
   PosRecord* comm_recv = nullptr;
+  // collective backend other than RCCL: a caller-supplied all-gather (mrs_swarm_comm_init_custom) or an in-process group of
+  // swarms driven by one host thread each (mrs_swarm_comm_init_loopback)
+  mrs_allgather_fn      comm_fn = nullptr;
+  void*                 comm_user = nullptr;
+  mrs_loopback_group_t* comm_group = nullptr;
+  // export-set exchange: between two searches only boundary UAVs travel
+  int       exchange = MRS_EXCHANGE_EXPORT_SETS;
+  bool      x_ok = false;           // export lists are live: the next tick can be a fused launch + export-set all-gather
+  int       x_fallback_left = 0;    // ticks to stay on the full exchange after an incomplete (overflowing) search
+  uint32_t* x_map_send = nullptr;   // [2 + n_max] slot map of this rank
+  uint32_t* x_map_recv = nullptr;   // [world][2 + n_max]
+  int64_t   x_export_count = 0;
+  std::vector<unsigned> x_last_overflow;
+  int       x_batch = 16;           // ticks enqueued between two looks at the stall word (MRS_EXPORT_BATCH)
+  int64_t   x_searches = 0, x_ticks = 0, x_noop_ticks = 0;
   double*   dS = nullptr;
   uint32_t* dF = nullptr;
   TypeParams* dT = nullptr;
@@ -670,6 +702,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->rccl_comm);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
+  if (s->x_map_send) (void)hipFree(s->x_map_send);
+  if (s->x_map_recv) (void)hipFree(s->x_map_recv);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -1199,7 +1233,7 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
   s->collision_ticks++;
   s->nbr_dirty = true;  // a later single-GPU tick starts from a rebuild
   if (s->use_lists)
-    HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, s->stream));
+    HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, 0, s->stream));
   else
     HIPCHK(mrs_collide_run(s->view(), &s->cwork, (const PosRecord*)dev_records, n_total, my_offset, crash, rebounce, 0, s->stream));
   return MRS_OK;
@@ -1209,6 +1243,7 @@ int mrs_swarm_handle_collisions(mrs_swarm_t* s, int32_t enabled, int32_t crash, 
   MRS_LOCK(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (!(crash || enabled)) return MRS_OK;  // src/multirotor_simulator.cpp:299-301
+  if (s->comm_world > 1) return fail(MRS_ERR_ARG, "this swarm is one shard of a sharded swarm: use mrs_swarm_tick_sharded_n (the collision pass is collective)");
   if (s->n == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   int rc;
@@ -1272,41 +1307,186 @@ int mrs_rccl_unique_id(const char* librccl_path, uint8_t* id128) {
   return MRS_OK;
 }
 
-int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total) {
-  MRS_ENTER(s);
-  if (!s || !id128) return fail(MRS_ERR_ARG, "null argument");
+// ---- in-process collective: `world` swarms of one process, one host thread each -------------------------------------------------
+struct mrs_loopback_group {
+  int                      world = 0;
+  std::atomic<int>         arrived{0};
+  std::atomic<unsigned>    generation{0};
+  std::vector<const void*> send;
+  std::vector<hipEvent_t>  ev_ready, ev_copied;
+  std::vector<int>         device;
+  std::atomic<int>         failed{0};
+  void barrier() {  // sense-reversing spin barrier (at most a handful of threads, all inside the same library call)
+    const unsigned gen = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
+      arrived.store(0, std::memory_order_relaxed);
+      generation.store(gen + 1, std::memory_order_release);
+    } else {
+      long spins = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (generation.load(std::memory_order_acquire) == gen) {
+        if (++spins > 2000) std::this_thread::yield();
+        // a peer that failed (or whose driver thread died) never arrives: give up instead of hanging the process
+        if ((spins & 0xFFFF) == 0 && (failed.load() || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))) {
+          failed.store(1);
+          return;
+        }
+      }
+    }
+  }
+};
+
+namespace {
+// all-gather among the swarms of a loopback group: every rank copies every rank's send buffer into its own receive buffer, device
+// to device on its own stream; events order the copies behind the producers and the producers' next writes behind the copies
+int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  hipError_t e = hipEventRecord(g->ev_ready[(size_t)rank], st);
+  g->send[(size_t)rank] = send;
+  if (e != hipSuccess) g->failed.store(1);
+  g->barrier();  // every rank has published its buffer and recorded "my send data is complete"
+  for (int q = 0; q < g->world && e == hipSuccess; q++) {
+    e = hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->send[(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
+  }
+  if (e == hipSuccess) e = hipEventRecord(g->ev_copied[(size_t)rank], st);
+  if (e != hipSuccess) g->failed.store(1);
+  g->barrier();  // every rank has enqueued its copies
+  for (int q = 0; q < g->world && e == hipSuccess; q++) e = hipStreamWaitEvent(st, g->ev_copied[(size_t)q], 0);  // nobody overwrites a buffer a peer still reads
+  if (e != hipSuccess || g->failed.load()) return fail(MRS_ERR_HIP, std::string("loopback all-gather: ") + hipGetErrorString(e));
+  return MRS_OK;
+}
+
+int comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
+  if (s->rccl_comm) return rccl_check(g_rccl.AllGather(send, recv, bytes, /*ncclInt8*/ 0, s->rccl_comm, s->stream), "ncclAllGather");
+  if (s->comm_group) return loopback_allgather(s->comm_group, s->comm_rank, send, recv, bytes, s->stream);
+  if (s->comm_fn) {
+    const int rc = s->comm_fn(s->comm_user, send, recv, (uint64_t)bytes, (void*)s->stream);
+    return rc == 0 ? MRS_OK : fail(MRS_ERR_HIP, "the caller's all-gather failed with code " + std::to_string(rc));
+  }
+  return fail(MRS_ERR_ARG, "no communicator");
+}
+
+int comm_setup(mrs_swarm* s, int world, int rank, int64_t n_total) {
   if (world < 1 || rank < 0 || rank >= world || n_total < s->n) return fail(MRS_ERR_ARG, "bad communicator shape");
+  if (s->comm_world > 0) return fail(MRS_ERR_ARG, "communicator already initialised");
   const int64_t base = n_total / world, rem = n_total % world;
-  const int64_t mine = base + (rank < rem ? 1 : 0);  // static contiguous index shards, sizes differ by at most one
+  const int64_t mine = base + (rank < rem ? 1 : 0);  // equal-count shards, sizes differ by at most one
   if (mine != s->n) return fail(MRS_ERR_ARG, "this swarm does not hold the shard of its rank (n_total / world UAVs, the first n_total % world ranks one more)");
-  HIPCHK(hipSetDevice(s->device));
-  int rc = rccl_load(librccl_path);
-  if (rc) return rc;
-  if (s->rccl_comm) return fail(MRS_ERR_ARG, "communicator already initialised");
-  NcclId id;
-  memcpy(id.internal, id128, 128);
-  if ((rc = rccl_check(g_rccl.CommInitRank(&s->rccl_comm, world, id, rank), "ncclCommInitRank"))) return rc;
+  return MRS_OK;
+}
+
+int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   s->comm_world   = world;
   s->comm_rank    = rank;
   s->comm_n_total = n_total;
   s->comm_n_max   = (n_total + world - 1) / world;
+  if (s->comm_n_max < 1) s->comm_n_max = 1;
+  s->x_ok         = false;
+  s->x_last_overflow.assign((size_t)world, 0u);
+  if (const char* e = getenv("MRS_EXPORT_BATCH")) s->x_batch = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = getenv("MRS_EXCHANGE")) s->exchange = atoi(e) == 1 ? MRS_EXCHANGE_FULL_GATHER : MRS_EXCHANGE_EXPORT_SETS;
   HIPCHK(hipMalloc(&s->comm_send, sizeof(PosRecord) * (size_t)s->comm_n_max));
   HIPCHK(hipMalloc(&s->comm_recv, sizeof(PosRecord) * (size_t)s->comm_n_max * (size_t)world));
+  HIPCHK(hipMalloc(&s->x_map_send, sizeof(uint32_t) * (size_t)(s->comm_n_max + 2)));
+  HIPCHK(hipMalloc(&s->x_map_recv, sizeof(uint32_t) * (size_t)(s->comm_n_max + 2) * (size_t)world));
   HIPCHK(hipMemsetAsync(s->comm_send, 0xFF, sizeof(PosRecord) * (size_t)s->comm_n_max, s->stream));  // NaN padding records never collide
+  return MRS_OK;
+}
+}  // namespace
+
+int mrs_swarm_comm_init(mrs_swarm_t* s, const char* librccl_path, int32_t world, int32_t rank, const uint8_t* id128, int64_t n_total) {
+  MRS_ENTER(s);
+  if (!s || !id128) return fail(MRS_ERR_ARG, "null argument");
+  int rc = comm_setup(s, world, rank, n_total);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = rccl_load(librccl_path))) return rc;
+  NcclId id;
+  memcpy(id.internal, id128, 128);
+  if ((rc = rccl_check(g_rccl.CommInitRank(&s->rccl_comm, world, id, rank), "ncclCommInitRank"))) return rc;
+  return comm_buffers(s, world, rank, n_total);
+}
+
+int mrs_swarm_comm_init_custom(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, mrs_allgather_fn fn, void* user) {
+  MRS_ENTER(s);
+  if (!s || !fn) return fail(MRS_ERR_ARG, "null argument");
+  int rc = comm_setup(s, world, rank, n_total);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  s->comm_fn   = fn;
+  s->comm_user = user;
+  return comm_buffers(s, world, rank, n_total);
+}
+
+int mrs_loopback_group_create(int32_t world, mrs_loopback_group_t** out) {
+  if (!out || world < 1 || world > 64) return fail(MRS_ERR_ARG, "bad loopback group size");
+  mrs_loopback_group* g = new mrs_loopback_group();
+  g->world = world;
+  g->send.assign((size_t)world, nullptr);
+  g->ev_ready.assign((size_t)world, nullptr);
+  g->ev_copied.assign((size_t)world, nullptr);
+  g->device.assign((size_t)world, -1);
+  *out = g;
+  return MRS_OK;
+}
+
+int mrs_loopback_group_destroy(mrs_loopback_group_t* g) {
+  if (!g) return MRS_OK;
+  for (int q = 0; q < g->world; q++) {
+    if (g->device[(size_t)q] >= 0) (void)hipSetDevice(g->device[(size_t)q]);
+    if (g->ev_ready[(size_t)q]) (void)hipEventDestroy(g->ev_ready[(size_t)q]);
+    if (g->ev_copied[(size_t)q]) (void)hipEventDestroy(g->ev_copied[(size_t)q]);
+  }
+  delete g;
+  return MRS_OK;
+}
+
+int mrs_swarm_comm_init_loopback(mrs_swarm_t* s, mrs_loopback_group_t* g, int32_t rank, int64_t n_total) {
+  MRS_ENTER(s);
+  if (!s || !g) return fail(MRS_ERR_ARG, "null argument");
+  int rc = comm_setup(s, g->world, rank, n_total);
+  if (rc) return rc;
+  if (g->ev_ready[(size_t)rank]) return fail(MRS_ERR_ARG, "this rank of the loopback group is taken");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipEventCreateWithFlags(&g->ev_ready[(size_t)rank], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g->ev_copied[(size_t)rank], hipEventDisableTiming));
+  g->device[(size_t)rank] = s->device;
+  s->comm_group           = g;
+  return comm_buffers(s, g->world, rank, n_total);
+}
+
+int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange) {
+  MRS_ENTER(s);
+  if (!s || (exchange != MRS_EXCHANGE_FULL_GATHER && exchange != MRS_EXCHANGE_EXPORT_SETS)) return fail(MRS_ERR_ARG, "bad exchange");
+  if (exchange != s->exchange) {
+    s->x_ok = false;
+    mrs_collide_invalidate_gathered(s->cwork);  // the two exchanges keep their neighbour lists in different forms
+  }
+  s->exchange = exchange;
   return MRS_OK;
 }
 
 int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
-  if (!s->rccl_comm) return MRS_OK;
+  if (s->comm_world == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
-  int rc = rccl_check(g_rccl.CommDestroy(s->rccl_comm), "ncclCommDestroy");
-  s->rccl_comm = nullptr;
+  int rc = MRS_OK;
+  if (s->rccl_comm) rc = rccl_check(g_rccl.CommDestroy(s->rccl_comm), "ncclCommDestroy");
+  s->rccl_comm  = nullptr;
+  s->comm_fn    = nullptr;
+  s->comm_user  = nullptr;
+  s->comm_group = nullptr;
+  s->comm_world = 0;
+  s->x_ok       = false;
+  mrs_collide_invalidate_gathered(s->cwork);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
+  if (s->x_map_send) (void)hipFree(s->x_map_send);
+  if (s->x_map_recv) (void)hipFree(s->x_map_recv);
   s->comm_send = s->comm_recv = nullptr;
+  s->x_map_send = s->x_map_recv = nullptr;
   return rc;
 }
 
@@ -1314,13 +1494,24 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
   MRS_ENTER(s);
   if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
   memset(out, 0, sizeof *out);
-  if (!s->rccl_comm) return MRS_OK;
+  if (s->comm_world == 0) return MRS_OK;
   out->world    = s->comm_world;
   out->rank     = s->comm_rank;
   out->n_total  = s->comm_n_total;
-  out->exchange = MRS_EXCHANGE_FULL_GATHER;
-  out->bytes_per_tick = (int64_t)sizeof(PosRecord) * s->comm_n_max;
-  if (g_rccl.CommCount) {
+  out->exchange = s->exchange;
+  const int64_t full = (int64_t)sizeof(PosRecord) * s->comm_n_max;
+  if (s->exchange == MRS_EXCHANGE_EXPORT_SETS) {
+    out->export_capacity   = mrs_collide_export_capacity(s->cwork);
+    out->export_count      = s->x_export_count;
+    out->bytes_per_tick    = (int64_t)sizeof(Pos4) * (1 + out->export_capacity);
+    out->bytes_per_rebuild = full + (int64_t)sizeof(uint32_t) * (s->comm_n_max + 2);
+  } else {
+    out->bytes_per_tick = out->bytes_per_rebuild = full;
+  }
+  out->ticks      = s->x_ticks;
+  out->searches   = s->x_searches;
+  out->noop_ticks = s->x_noop_ticks;
+  if (s->rccl_comm && g_rccl.CommCount) {
     int c = 0;
     int rc = rccl_check(g_rccl.CommCount(s->rccl_comm, &c), "ncclCommCount");
     if (rc) return rc;
@@ -1329,35 +1520,200 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
   return MRS_OK;
 }
 
-// timerMain on every rank of a sharded swarm: step, pack, ONE all-gather of the 48-B records on the swarm's own stream, collision
-// pass against the gathered records — no host synchronisation and no other stream inside the loop
-int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
-  MRS_ENTER(s);
-  if (!s) return fail(MRS_ERR_ARG, "null swarm");
-  if (!s->rccl_comm) return fail(MRS_ERR_ARG, "mrs_swarm_comm_init has not been called");
-  if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
-  if (n_ticks == 0) return MRS_OK;
-  HIPCHK(hipSetDevice(s->device));
-  int rc = upload_types(s, dt);
-  if (rc) return rc;
-  if ((rc = begin_profile(s))) return rc;
+// UAVs sorted by x (ties: by public index), cut into equal-count slabs by the caller
+int mrs_slab_partition(const double* pos_xyz, int64_t n_total, int32_t world, int64_t* order) {
+  if (!pos_xyz || !order || n_total < 0 || world < 1) return fail(MRS_ERR_ARG, "bad partition arguments");
+  for (int64_t k = 0; k < n_total; k++) order[k] = k;
+  std::stable_sort(order, order + n_total, [&](int64_t a, int64_t b) {
+    const double xa = pos_xyz[3 * a], xb = pos_xyz[3 * b];
+    if (xa != xa || xb != xb) return (xa == xa) && (xb != xb);  // NaN positions last
+    return xa < xb;
+  });
+  return MRS_OK;
+}
+
+// ---- sharded ticks ----------------------------------------------------------------------------------------------------------------
+namespace {
+
+// every tick gathers all records (MRS_EXCHANGE_FULL_GATHER, and the fallback of the export-set exchange when some UAV has more
+// neighbours than its list holds): step, pack, ONE all-gather of the 48-B records, collision pass against the gathered records
+int full_gather_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide& c) {
   const int64_t n_rec = s->comm_n_max * s->comm_world;
+  int           rc;
+  s->x_ok    = false;
+  s->p_valid = false;
+  s->fk_ok   = false;
   for (int k = 0; k < n_ticks; k++) {
     if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
-    if (!(crash || enabled)) continue;  // src/multirotor_simulator.cpp:299-301
     if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
-    if ((rc = rccl_check(g_rccl.AllGather(s->comm_send, s->comm_recv, (size_t)s->comm_n_max * 6, /*ncclFloat64*/ 8, s->rccl_comm, s->stream),
-                         "ncclAllGather")))
-      return rc;
+    if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)s->comm_n_max))) return rc;
+    s->x_ticks++;
     if (s->n == 0) continue;
     s->fext_active = true;
     s->collision_ticks++;
     s->nbr_dirty = true;
     if (s->use_lists)
-      HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, crash, rebounce, s->stream));
+      HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, c.crash, c.rebounce, 0, s->stream));
     else
-      HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, crash, rebounce, 0, s->stream));
+      HIPCHK(mrs_collide_run(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)s->comm_rank * s->comm_n_max, c.crash, c.rebounce, 0, s->stream));
   }
+  return MRS_OK;
+}
+
+// The tick after the most recent step on the SEARCH path of the export-set exchange: gather all records, search (which evaluates
+// this tick's handleCollisions), then derive the export sets and rewrite the lists.  Collective.  Returns 1 when the lists came out
+// incomplete (a UAV with more neighbours than its list holds, on any rank): the caller stays on the full exchange for a while.
+int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
+  const int     world = s->comm_world, rank = s->comm_rank;
+  const int64_t n_max = s->comm_n_max, n_rec = n_max * world, stride = n_max + 2;
+  int           rc;
+  *incomplete = 0;
+  s->x_ok     = false;
+  s->x_searches++;
+  if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
+  if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)n_max))) return rc;
+  s->fext_active = true;
+  s->nbr_dirty   = true;  // (a later single-GPU tick starts from a search of its own)
+  if (s->n > 0)
+    HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
+  long long cap = mrs_collide_export_capacity(s->cwork);
+  HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, s->stream));
+  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, rank, s->x_map_send, s->stream));
+  if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
+  // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
+  std::vector<unsigned> heads((size_t)world * 2);
+  HIPCHK(hipMemcpy2DAsync(heads.data(), 2 * sizeof(unsigned), s->x_map_recv, sizeof(uint32_t) * (size_t)stride, 2 * sizeof(unsigned), (size_t)world,
+                          hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  long long need = 0;
+  for (int q = 0; q < world; q++) {
+    if ((long long)heads[(size_t)q * 2] > need) need = heads[(size_t)q * 2];
+    if (heads[(size_t)q * 2 + 1] != s->x_last_overflow[(size_t)q]) *incomplete = 1;
+    s->x_last_overflow[(size_t)q] = heads[(size_t)q * 2 + 1];
+  }
+  s->x_export_count = heads[(size_t)rank * 2];
+  if (*incomplete) {
+    mrs_collide_invalidate_gathered(s->cwork);
+    return MRS_OK;
+  }
+  if (need > cap || cap == 0) {  // grow with headroom: the sets change from search to search
+    long long ncap = ((need + need / 2 + 64 + 63) / 64) * 64;
+    HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, ncap, s->stream));
+  }
+  HIPCHK(mrs_collide_export_translate(s->view(), s->cwork, n_max, rank, s->x_map_recv, s->comm_recv, s->stream));
+  mrs_collide_invalidate_gathered(s->cwork);  // the lists are in export form now: the full exchange would start with a search
+  s->x_ok = true;
+  s->tau  = 0;
+  return MRS_OK;
+}
+
+int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval) {
+  if (s->n > 0) {
+    CollDev  cd;
+    SwarmDev v = s->view();
+    HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
+    s->region_launches++;
+    const int variant = s->n_cascade > 0 ? 0 : 1;
+    if (s->arith == MRS_ARITH_FAST)
+      HIPCHK(mrs_launch_step_coll_fast(v, cd, dt, variant, s->stream));
+    else
+      HIPCHK(mrs_launch_step_coll_literal(v, cd, dt, variant, s->stream));
+    mrs_collide_fused_advance(s->cwork);
+  }
+  s->tau++;
+  const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
+  return comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
+}
+
+int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide& c) {
+  const volatile unsigned* hw;
+  int  rc, done = 0;
+  bool pending = false;  // the collision tick after the most recent step has not been evaluated yet
+  s->p_valid = false;    // (single-GPU lazies do not mix with this path)
+  s->fk_ok   = false;
+  while (done < n_ticks) {
+    if (s->x_fallback_left > 0) {
+      const int k = n_ticks - done < s->x_fallback_left ? n_ticks - done : s->x_fallback_left;
+      if ((rc = full_gather_ticks(s, dt, k, c))) return rc;
+      s->x_fallback_left -= k;
+      done += k;
+      continue;
+    }
+    if (!s->x_ok) {  // no usable export lists (first tick, host writes, lists gone stale): this tick on the search path
+      if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
+      int incomplete = 0;
+      if ((rc = export_search(s, c, &incomplete))) return rc;
+      s->collision_ticks++;
+      s->x_ticks++;
+      done++;
+      if (incomplete) s->x_fallback_left = 64;
+      continue;
+    }
+    const int b = n_ticks - done < s->x_batch ? n_ticks - done : s->x_batch;
+    mrs_swarm::Collide off;
+    for (int t = 0; t < b; t++) {
+      if ((rc = launch_fused_export(s, dt, pending ? c : off))) return rc;
+      pending = true;
+    }
+    HIPCHK(mrs_collide_export_fold_stall(s->cwork, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hw = mrs_collide_host_words(s->cwork);
+    const unsigned T = hw[CTL_STALL];  // identical on every rank: the stall words travel in the headers of the collective
+    const int ran = (T == 0u || (int)T > b) ? b : (int)T;
+    done += ran;
+    s->x_ticks += ran;
+    s->collision_ticks += ran;
+    s->tau = 0;
+    if (T != 0u) {  // some UAV (of some rank) left its skin during step T: launches T+1.. of the batch did nothing
+      s->x_noop_ticks += b - ran;
+      int incomplete = 0;
+      if ((rc = export_search(s, c, &incomplete))) return rc;  // evaluates the collision tick after step T
+      pending = false;
+      if (incomplete) s->x_fallback_left = 64;
+    } else {
+      HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));  // (progress word / tick numbering start over)
+    }
+  }
+  if (pending && s->n > 0) {  // the last tick's handleCollisions: the export buffer holds the positions after the last step
+    CollDev  cd;
+    SwarmDev v = s->view();
+    HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, 1u, 1, c.crash, c.rebounce, &cd));
+    cd.p_out = nullptr;
+    HIPCHK(mrs_collide_export_eval(v, cd, s->stream));
+  }
+  unsigned w[8];
+  HIPCHK(mrs_collide_fused_words(s->cwork, s->stream, w));
+  if (w[CTL_BADSLOT]) return fail(MRS_ERR_HIP, "export-set exchange: a listed foreign UAV is not in its owner's export set (" + std::to_string(w[CTL_BADSLOT]) + " entries)");
+  return MRS_OK;
+}
+}  // namespace
+
+// timerMain on every rank of a sharded swarm (no host synchronisation inside a batch of ticks, everything on the swarm's stream)
+int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce) {
+  MRS_ENTER(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (s->comm_world == 0) return fail(MRS_ERR_ARG, "mrs_swarm_comm_init has not been called");
+  if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
+  if (n_ticks == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, dt);
+  if (rc) return rc;
+  // Host writes since the last sharded tick (set_state, set_mass, ... possibly on this rank only) do not touch x_ok: all ranks must
+  // take the same path.  The first fused launch notices them on the device — a UAV away from its recorded position or with other
+  // airframe constants than its record raises the stall word, which travels to every rank in the collective's headers.
+  if ((rc = begin_profile(s))) return rc;
+  if (!(crash || enabled)) {  // src/multirotor_simulator.cpp:299-301: no collision pass, no exchange
+    for (int k = 0; k < n_ticks; k++)
+      if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
+    return finish_profile(s);
+  }
+  const mrs_swarm::Collide c{true, enabled, crash, rebounce};
+  if (s->exchange == MRS_EXCHANGE_EXPORT_SETS && s->use_lists && s->use_fused)
+    rc = export_ticks(s, dt, n_ticks, c);
+  else
+    rc = full_gather_ticks(s, dt, n_ticks, c);
+  if (rc) return rc;
+  s->nbr_dirty = false;
   return finish_profile(s);
 }
 

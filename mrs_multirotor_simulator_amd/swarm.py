@@ -63,7 +63,11 @@ OUTPUT_DTYPE = np.dtype([("position", "f8", 3), ("orientation", "f8", 4), ("velo
 class CommInfo(C.Structure):
     """mrs_comm_info_t"""
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("rccl_ranks", C.c_int32), ("exchange", C.c_int32), ("n_total", C.c_int64),
-                ("bytes_per_tick", C.c_int64), ("bytes_per_rebuild", C.c_int64), ("export_count", C.c_int64), ("export_capacity", C.c_int64)]
+                ("bytes_per_tick", C.c_int64), ("bytes_per_rebuild", C.c_int64), ("export_count", C.c_int64), ("export_capacity", C.c_int64),
+                ("ticks", C.c_int64), ("searches", C.c_int64), ("noop_ticks", C.c_int64)]
+
+
+EXCHANGE_NONE, EXCHANGE_FULL_GATHER, EXCHANGE_EXPORT_SETS = 0, 1, 2
 
 
 EXCHANGE_NAMES = {0: "none", 1: "full all-gather of 48-B records per tick", 2: "export-set all-gather (boundary UAVs only), full gather on search ticks"}
@@ -86,10 +90,14 @@ ABI_SYMBOLS = [
     "mrs_swarm_get_state", "mrs_swarm_set_state", "mrs_swarm_get_imu", "mrs_swarm_get_external_force",
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
+    "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
+    "mrs_slab_partition",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
 _lib = None
+# mrs_allgather_fn: int (*)(void* user, const void* send, void* recv, uint64_t bytes_per_rank, void* stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 def _preload_hip_runtime():
@@ -139,6 +147,37 @@ def rccl_unique_id(librccl_path=None):
     buf = (C.c_uint8 * 128)()
     _check(_lib.mrs_rccl_unique_id(path.encode() if path else None, C.cast(buf, C.c_void_p)))
     return bytes(buf)
+
+
+def slab_partition(pos, world):
+    """mrs_slab_partition: public indices sorted by x; rank r of `world` equal-count slabs holds order[lo_r:hi_r] (sharded.shard_range)."""
+    load_library()
+    pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+    order = np.zeros(len(pos), dtype=np.int64)
+    _check(_lib.mrs_slab_partition(_dp(pos), len(pos), int(world), order.ctypes.data_as(C.POINTER(C.c_int64))))
+    return order
+
+
+class LoopbackGroup:
+    """mrs_loopback_group_t: `world` swarms of this process exchanging through device-to-device copies; every swarm must be driven by
+    its own host thread (tick_sharded_n is collective)."""
+
+    def __init__(self, world):
+        load_library()
+        self._h = C.c_void_p()
+        self.world = int(world)
+        _check(_lib.mrs_loopback_group_create(self.world, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.mrs_loopback_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def load_library():
@@ -201,6 +240,12 @@ def load_library():
         "mrs_swarm_tick_sharded_n": [vp, f64, i32, i32, i32, f64],
         "mrs_swarm_comm_destroy": [vp],
         "mrs_swarm_comm_info": [vp, C.POINTER(CommInfo)],
+        "mrs_swarm_comm_init_custom": [vp, i32, i32, C.c_int64, ALLGATHER_FN, vp],
+        "mrs_loopback_group_create": [i32, C.POINTER(vp)],
+        "mrs_loopback_group_destroy": [vp],
+        "mrs_swarm_comm_init_loopback": [vp, vp, i32, C.c_int64],
+        "mrs_swarm_set_exchange": [vp, i32],
+        "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -392,8 +437,21 @@ class Swarm:
         ci = CommInfo()
         _check(_lib.mrs_swarm_comm_info(self._h, C.byref(ci)))
         d = {k: int(getattr(ci, k)) for k, _ in CommInfo._fields_}
-        d["parallelism"] = f"{d['world']} index shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, RCCL"
+        d["parallelism"] = (f"{d['world']} equal-count shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, "
+                            + ("RCCL" if d["rccl_ranks"] else "in-process / caller-supplied collective"))
         return d
+
+    def comm_init_loopback(self, group, rank, n_total):
+        _check(_lib.mrs_swarm_comm_init_loopback(self._h, group._h, int(rank), int(n_total)))
+        self._group = group  # keep it alive as long as the swarm uses it
+
+    def comm_init_custom(self, world, rank, n_total, fn):
+        """fn(user, send_ptr, recv_ptr, bytes_per_rank, stream_ptr) -> 0; kept alive by the swarm"""
+        self._allgather_cb = ALLGATHER_FN(fn)
+        _check(_lib.mrs_swarm_comm_init_custom(self._h, int(world), int(rank), int(n_total), self._allgather_cb, None))
+
+    def set_exchange(self, exchange):
+        _check(_lib.mrs_swarm_set_exchange(self._h, int(exchange)))
 
     # -- state --
     def get_state(self, first=0, count=None):

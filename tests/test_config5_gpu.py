@@ -1,8 +1,9 @@
 """BASELINE configs[4] ("config 5") AT ITS SIZE on one GPU: 1 000 000 UAVs with mutual collisions, sharded 8 x 125 000.
 
-The eight ranks of the real run are eight `Swarm` objects on the one device of the test box ("virtual shards"); what RCCL's
-all-gather would deliver is assembled in a device buffer the shards write their records into.  Everything else — step kernels,
-record packing, the gathered collision pass with its neighbour lists — is the code path of the 8-GPU run.  Checked against
+The eight ranks of the real run are eight `Swarm` objects on the one device of the test box ("virtual shards"), x-sorted slabs of
+the swarm, each driven by its own host thread through mrs_swarm_tick_sharded_n; an in-process loopback group stands in for RCCL's
+all-gather (device-to-device copies).  Everything else — fused step + collision launches, export-set exchange, searches over the
+full gather, stall / replay protocol, order of the collectives — is the code path of the 8-GPU run.  Checked against
   (1) a single 1 000 000-UAV swarm driven by mrs_swarm_tick_n (whole-swarm comparison), and
   (2) the CPU oracle on a sample that is CLOSED under interaction: whole connected components of the "closer than 2.5 m at
       t = 0" graph.  UAVs of different components start >= 2.5 m apart and move < 0.6 m in the test's ticks, so they never come
@@ -62,38 +63,24 @@ def make_swarm(M, n, st, cmd, sl, arith):
 
 
 def test_config5_one_million_uavs_eight_virtual_shards(mrs, oracle):
-    import torch
-    from mrs_multirotor_simulator_amd.sharded import max_shard, shard_range
+    from mrs_multirotor_simulator_amd.sharded import max_shard
     M = mrs
     ticks = 60
     rng = np.random.default_rng(50)
     st, cmd, planted = config5_scenario(N_TOTAL)
     pick = closed_sample(st["x"], planted[:1500], 24_000, rng)
 
-    # (a) eight virtual shards, the gathered exchange
-    n_max = max_shard(N_TOTAL, WORLD)
-    recv = torch.full((WORLD * n_max, 6), float("nan"), dtype=torch.float64, device="cuda")
-    shards = []
-    for r in range(WORLD):
-        lo, hi = shard_range(N_TOTAL, WORLD, r)
-        shards.append((make_swarm(M, hi - lo, st, cmd, slice(lo, hi), M.ARITH_FAST), lo, hi))
-    for _ in range(ticks):
-        for r, (g, lo, hi) in enumerate(shards):
-            g.step(DT)
-            g.pack_positions_to(recv[r * n_max:].data_ptr())
-        for g, _, _ in shards:
-            g.synchronize()
-        for r, (g, lo, hi) in enumerate(shards):
-            g.handle_collisions_gathered(recv.data_ptr(), WORLD * n_max, r * n_max, True, False, 100.0)
-        for g, _, _ in shards:
-            g.synchronize()  # every shard has read the gathered buffer before anyone's next pack overwrites its block
-    sh = {k: np.concatenate([g.get_state()[k] for g, _, _ in shards]) for k in ("x", "v", "R", "omega", "motor_rpm")}
-    sh["f"] = np.concatenate([g.get_external_force() for g, _, _ in shards])
-    sh["pid"] = np.concatenate([g.get_pid() for g, _, _ in shards])
-    sh["imu"] = np.concatenate([g.get_imu() for g, _, _ in shards])
-    stats = [g.collision_stats() for g, _, _ in shards]
-    del shards, recv
-
+    # (a) eight virtual shards (x-sorted slabs, public index kept through the permutation), the export-set exchange over an
+    #     in-process loopback group: one host thread per rank, as eight processes would run it over RCCL
+    from test_export_sets_gpu import VirtualShards
+    order = M.slab_partition(st["x"], WORLD)
+    vs = VirtualShards(M, WORLD, order, M.model_params("x500", ground_enabled=True), None, None, st, M.POSITION_CMD, cmd, M.ARITH_FAST,
+                       M.EXCHANGE_EXPORT_SETS)
+    vs.tick_n(ticks, True, False, 100.0)
+    sh = vs.gather()
+    stats = vs.info()
+    vs.close()
+    del vs
     # (b) the same million UAVs as ONE swarm
     one = make_swarm(M, N_TOTAL, st, cmd, slice(0, N_TOTAL), M.ARITH_FAST)
     one.tick_n(DT, ticks, True, False, 100.0)
@@ -105,6 +92,7 @@ def test_config5_one_million_uavs_eight_virtual_shards(mrs, oracle):
     # different kernel instantiations (three-wave build at 1 M, two-wave at 125 k) choose their FMAs differently: ~1e-12 per step
     for k in ("x", "v", "R", "omega", "motor_rpm", "f", "pid", "imu"):
         helpers.assert_close(sh[k], so[k], 1e-9, f"8 shards vs one swarm: {k}")
+    assert np.array_equal(sh["crashed"], np.zeros(N_TOTAL, dtype=np.int32))
     helpers.assert_close_per_uav(sh, so, 1e-9, "8 shards vs one swarm", fields=("x", "v", "R", "omega", "motor_rpm", "f"))
     assert np.abs(so["v"]).max() * ticks * DT < 0.6, "the closed-sample argument needs slow UAVs"
 
@@ -125,8 +113,14 @@ def test_config5_one_million_uavs_eight_virtual_shards(mrs, oracle):
         helpers.assert_close(got[k], ref[k], RTOL_NORTH_STAR, f"shards vs oracle sample: {k}")
     worst, err = helpers.assert_close_per_uav(got, ref, RTOL_NORTH_STAR, "shards vs oracle sample",
                                               fields=("x", "v", "R", "omega", "motor_rpm", "f"))
-    per_shard = np.bincount(np.minimum(pick // n_max, WORLD - 1), minlength=WORLD)
+    n_max = max_shard(N_TOTAL, WORLD)
+    rank_of = np.empty(N_TOTAL, dtype=np.int64)
+    rank_of[order] = np.minimum(np.arange(N_TOTAL) // n_max, WORLD - 1)
+    per_shard = np.bincount(rank_of[pick], minlength=WORLD)
     assert per_shard.min() >= 2000, per_shard
     print(f"config 5: {N_TOTAL} UAVs, {WORLD} virtual shards, {ticks} ticks; {touched} UAVs under a collision force at the end; oracle sample "
           f"{m} UAVs ({per_shard.min()}..{per_shard.max()} per shard), worst per-UAV error {err:.2e} (UAV {pick[worst]}); "
-          f"(collision ticks, searches) per shard: {stats}")
+          f"rank 0: {stats[0]}")
+    for ci in stats:
+        assert ci["ticks"] == ticks and ci["searches"] < ticks // 3, ci
+        assert ci["bytes_per_tick"] * 8 < ci["bytes_per_rebuild"], ci  # slab shards: the boundary sets are a small part of a shard
