@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
                     help="the 1 000 000-UAV collision leg (BASELINE configs[4]); auto = whenever N > 1")
     ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
+    ap.add_argument("--config5-shards", choices=["slabs", "index"], default="slabs", help="x-sorted slabs (boundary sets stay small) or index ranges")
+    ap.add_argument("--config5-exchange", choices=["export", "full"], default="export",
+                    help="export: boundary UAVs only between two searches; full: all 48-B records on every tick")
     return ap.parse_args()
 
 
@@ -321,6 +324,9 @@ def headline_leg(args, R):
         if coll:
             ticks, searches = sw.collision_stats()
             out["config"]["collision_ticks"], out["config"]["neighbour_searches"] = int(ticks), int(searches)
+            fused, stalls, replayed = sw.fused_stats()
+            out["config"]["ticks_evaluated_by_the_next_step_launch"], out["config"]["stale_list_stalls"] = int(fused), int(stalls)
+            out["config"]["launches_replayed"] = int(replayed)
             p = 0.06  # fraction of UAVs with a listed partner at 64 m^3 per UAV
             cb = COLLISION_BYTES["list_tick_per_uav"] + COLLISION_BYTES["list_tick_per_uav_with_partner"] * p
             out["roofline_collision"] = {
@@ -346,10 +352,12 @@ def config5_leg(args, R):
     lo, hi = shard_range(n_total, R.world, R.rank)
     n = hi - lo
     st, cmd = make_inputs(n_total, "position+collisions", seed=5, volume_per_uav=args.volume_per_uav)  # every rank draws the same swarm
+    # spatially coherent shards: x-sorted, equal-count slabs; `own` = the public indices this rank holds
+    own = M.slab_partition(st["x"], R.world)[lo:hi] if args.config5_shards == "slabs" else np.arange(lo, hi)
     sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
     sw.construct(0, n, M.model_params("x500", ground_enabled=True))
-    sw.set_state(0, n, st["x"][lo:hi], st["v"][lo:hi], st["R"][lo:hi], st["omega"][lo:hi], st["motor_rpm"][lo:hi])
-    sw.set_input(0, n, M.POSITION_CMD, cmd[lo:hi])
+    sw.set_state(0, n, st["x"][own], st["v"][own], st["R"][own], st["omega"][own], st["motor_rpm"][own])
+    sw.set_input(0, n, M.POSITION_CMD, cmd[own])
     del st, cmd
     uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
     if R.rank == 0:
@@ -357,6 +365,7 @@ def config5_leg(args, R):
     if R.use_dist:
         dist.broadcast(uid, 0)
     sw.comm_init(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()), n_total)
+    sw.set_exchange(M.EXCHANGE_FULL_GATHER if args.config5_exchange == "full" else M.EXCHANGE_EXPORT_SETS)
 
     def run(k):
         sw.tick_sharded_n(DT, k, True, False, 100.0)
@@ -374,7 +383,11 @@ def config5_leg(args, R):
            "value": n_total * steps / el, "unit": "UAV-steps/s", "ms_per_tick": el / steps * 1e3, "n_total": n_total, "n_gpus": R.world,
            "steps": steps, "warmup": warmup, "regions": len(times), "scaling": "strong",
            "parallelism": info["parallelism"], "rccl_ranks": info["rccl_ranks"],
-           "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collision_ticks": int(ticks), "neighbour_searches": int(searches)}
+           "shards": args.config5_shards,
+           "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collective_bytes_per_rank_per_search_tick": info["bytes_per_rebuild"],
+           "export_set_of_rank0": info["export_count"], "export_capacity": info["export_capacity"], "uavs_per_rank": n,
+           "sharded_ticks": info["ticks"], "search_ticks": info["searches"], "replayed_noop_ticks": info["noop_ticks"],
+           "collision_ticks": int(ticks), "neighbour_searches": int(searches)}
     sw.comm_destroy()
     del sw
     return out if R.rank == 0 else None

@@ -335,7 +335,7 @@ struct mrs_swarm {
   uint32_t             tau = 0;                     // tick index of the last fused launch since the stream was last drained
   bool                 use_fused = true;            // tuning: MRS_FUSED_COLLISIONS=0 launches every collision tick on its own
   int                  fused_lead = 8;              // launches the host may run ahead of the device (MRS_FUSED_LEAD)
-  int64_t              n_stalls = 0, n_noop_launches = 0;
+  int64_t              n_stalls = 0, n_noop_launches = 0, n_fused = 0;
   // profiling
   int  profiling = 0;  // 0 off, 1 one event pair around the whole step_n/tick_n region, 2 one pair per step launch
   std::vector<hipEvent_t> ev;
@@ -1074,6 +1074,7 @@ static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
   if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
   mrs_collide_fused_advance(s->cwork);
   s->tau++;
+  s->n_fused++;
   s->log.push_back(e);
   if (e.eval.on) s->fext_active = true;
   return MRS_OK;
@@ -1964,6 +1965,15 @@ int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_r
   HIPCHK(mrs_collide_rebuilds(s->cwork, s->stream, &rb));
   if (n_ticks) *n_ticks = s->collision_ticks;
   if (n_rebuilds) *n_rebuilds = s->use_lists ? (int64_t)rb : s->collision_ticks;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_fused_stats(mrs_swarm_t* s, int64_t* fused_launches, int64_t* stalls, int64_t* replayed_launches) {
+  MRS_ENTER(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (fused_launches) *fused_launches = s->n_fused;
+  if (stalls) *stalls = s->n_stalls;
+  if (replayed_launches) *replayed_launches = s->n_noop_launches;
   return MRS_OK;
 }
 

@@ -89,3 +89,127 @@ class ShardedSwarm:
         for _ in range(n_ticks):
             self.engine.step(dt)
             self.handle_collisions(enabled, crash, rebounce)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Export-set exchange driven from Python: the synchronous form of the protocol the library runs natively in
+# mrs_swarm_tick_sharded_n (swarm_host.hip: export_ticks / export_search).  Between two neighbour searches a rank only needs the
+# positions of the foreign UAVs within sqrt(3) + SKIN of one of its own at the last search, and — the relation being symmetric —
+# only has to publish the own UAVs that have such a foreign neighbour.  Per tick:
+#   step -> all-gather of [stale flag | padded export positions]
+#   nobody stale : collide against own UAVs + received exports            (24 B per EXPORTED UAV on the wire)
+#   somebody stale (moved > SKIN/2 since the search): all-gather of every record, search, new export sets, all-gather of the slot maps
+# The engine is anything with step(dt), records() -> (n_local, 6) array [x y z mass arm prop] and
+# collide(foreign_global_index, foreign_records, enabled, crash, rebounce); the world_size-2/-4 gloo tests run it on the CPU.
+SKIN = 0.5
+LIST_RADIUS = 3.0 ** 0.5 + SKIN
+
+
+def slab_order(pos, world):
+    """public indices sorted by x (stable): rank r holds order[shard_range(n, world, r)] — the numpy twin of mrs_slab_partition"""
+    import numpy as np
+    x = np.asarray(pos, dtype=np.float64)[:, 0]
+    return np.argsort(np.where(np.isnan(x), np.inf, x), kind="stable")
+
+
+class ExportSetSwarm:
+    def __init__(self, n_total, engine, device, group=None):
+        import numpy as np
+        self.np = np
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = n_total
+        self.lo, self.hi = shard_range(n_total, self.world, self.rank)
+        self.n_local, self.n_max = self.hi - self.lo, max_shard(n_total, self.world)
+        self.engine, self.device = engine, device
+        self.live = False          # export sets valid
+        self.cap = 0               # export slots per rank in the padded collective
+        self.stats = dict(ticks=0, searches=0, bytes_list_ticks=0, bytes_search_ticks=0)
+
+    def _allgather(self, t):
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=self.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(out.view(-1, *t.shape[1:]) if t.dim() > 1 else out.view(-1), t.contiguous(), group=self.group)
+        else:
+            out[0] = t
+        return out
+
+    def _search(self, rec):
+        """full gather + neighbour search + export sets.  Returns the gathered records (world, n_max, 6) as numpy."""
+        np = self.np
+        from scipy.spatial import cKDTree
+        send = torch.full((self.n_max, REC), float("nan"), dtype=torch.float64, device=self.device)
+        send[: self.n_local] = torch.from_numpy(rec)
+        allrec = self._allgather(send).cpu().numpy()
+        self.stats["searches"] += 1
+        self.stats["bytes_search_ticks"] += self.n_max * REC * 8
+        flat = allrec.reshape(-1, REC)
+        usable = np.isfinite(flat[:, :3]).all(axis=1)
+        mine = np.arange(self.rank * self.n_max, self.rank * self.n_max + self.n_local)
+        ui = np.flatnonzero(usable)  # NaN padding and non-finite positions take no part
+        tree = cKDTree(flat[ui, :3])
+        foreign_of = [[] for _ in range(self.n_local)]
+        for k, g in enumerate(mine):
+            if usable[g]:
+                for jj in tree.query_ball_point(flat[g, :3], LIST_RADIUS * (1 + 1e-12)):
+                    j = int(ui[jj])
+                    if j // self.n_max != self.rank:
+                        foreign_of[k].append(j)
+        exported = np.array([len(f) > 0 for f in foreign_of], dtype=bool)
+        self.exp_local = np.flatnonzero(exported)                       # own UAVs some other rank lists (symmetry)
+        slot = np.full(self.n_max + 1, -1, dtype=np.int64)
+        slot[0] = len(self.exp_local)
+        slot[1 + self.exp_local] = np.arange(len(self.exp_local))
+        maps = self._allgather(torch.from_numpy(slot).to(self.device)).cpu().numpy()
+        self.stats["bytes_search_ticks"] += (self.n_max + 1) * 8
+        self.cap = int(maps[:, 0].max())
+        # foreign UAVs this rank needs: (gathered slot g, position in the padded export collective)
+        need = sorted({j for f in foreign_of for j in f})
+        self.need_g = np.array(need, dtype=np.int64)
+        q, j = self.need_g // self.n_max, self.need_g % self.n_max
+        e = maps[q, 1 + j]
+        assert (e >= 0).all(), "a listed foreign UAV is not in its owner's export set: the relation must be symmetric"
+        self.need_slot = q * self.cap + e
+        self.need_const = flat[self.need_g, 3:]
+        self.ref_pos = rec[:, :3].copy()
+        self.ref_const = rec[:, 3:].copy()
+        self.live = True
+        return flat
+
+    def _global_index(self, g):
+        q, k = self.np.divmod(g, self.n_max)
+        base = self.np.array([shard_range(self.n_total, self.world, r)[0] for r in range(self.world)])
+        return base[q] + k
+
+    def tick(self, dt, enabled, crash, rebounce):
+        np = self.np
+        self.engine.step(dt)
+        self.stats["ticks"] += 1
+        if not (enabled or crash):
+            return
+        rec = np.asarray(self.engine.records(), dtype=np.float64).reshape(self.n_local, REC)
+        stale = 1.0
+        if self.live:
+            d2 = ((rec[:, :3] - self.ref_pos) ** 2).sum(axis=1)
+            ok_now, ok_ref = np.isfinite(rec[:, :3]).all(axis=1), np.isfinite(self.ref_pos).all(axis=1)
+            moved = (ok_now != ok_ref) | (ok_now & ok_ref & ~(d2 <= (0.5 * SKIN) ** 2 * (1 - 1e-9)))
+            stale = float(moved.any() or not np.array_equal(rec[:, 3:], self.ref_const))
+        send = torch.zeros((1 + self.cap, 3), dtype=torch.float64, device=self.device)
+        send[0, 0] = stale
+        if self.live and len(self.exp_local):
+            send[1: 1 + len(self.exp_local)] = torch.from_numpy(rec[self.exp_local, :3])
+        got = self._allgather(send).cpu().numpy()
+        self.stats["bytes_list_ticks"] += (1 + self.cap) * 24
+        if got[:, 0, 0].any():  # some rank's lists are stale: every rank searches (same decision everywhere)
+            flat = self._search(rec)
+            fg = np.array([g for g in range(len(flat)) if g // self.n_max != self.rank and np.isfinite(flat[g, 0])], dtype=np.int64)
+            # the search tick collides against every gathered record, like the full exchange
+            self.engine.collide(self._global_index(fg), flat[fg], enabled, crash, rebounce)
+            return
+        pos = got[:, 1:, :].reshape(-1, 3)[self.need_slot] if len(self.need_g) else np.zeros((0, 3))
+        self.engine.collide(self._global_index(self.need_g), np.concatenate([pos, self.need_const], axis=1), enabled, crash, rebounce)
+
+    def tick_n(self, dt, n_ticks, enabled, crash, rebounce):
+        for _ in range(n_ticks):
+            self.tick(dt, enabled, crash, rebounce)

@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
-    "mrs_slab_partition",
+    "mrs_slab_partition", "mrs_swarm_get_fused_stats",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -246,6 +246,7 @@ def load_library():
         "mrs_swarm_comm_init_loopback": [vp, vp, i32, C.c_int64],
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
+        "mrs_swarm_get_fused_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -399,6 +400,12 @@ class Swarm:
         a, b = C.c_int64(), C.c_int64()
         _check(_lib.mrs_swarm_get_collision_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def fused_stats(self):
+        """(collision ticks evaluated by the following step launch, stale-list stalls, launches replayed after a stall)"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.mrs_swarm_get_fused_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_profiling(self, enabled):
         _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))
