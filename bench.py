@@ -324,9 +324,9 @@ def headline_leg(args, R):
         if coll:
             ticks, searches = sw.collision_stats()
             out["config"]["collision_ticks"], out["config"]["neighbour_searches"] = int(ticks), int(searches)
-            fused, stalls, replayed = sw.fused_stats()
+            fused, stalls, replayed, ahead = sw.fused_stats()
             out["config"]["ticks_evaluated_by_the_next_step_launch"], out["config"]["stale_list_stalls"] = int(fused), int(stalls)
-            out["config"]["launches_replayed"] = int(replayed)
+            out["config"]["launches_replayed"], out["config"]["searches_queued_ahead"] = int(replayed), int(ahead)
             p = 0.06  # fraction of UAVs with a listed partner at 64 m^3 per UAV
             cb = COLLISION_BYTES["list_tick_per_uav"] + COLLISION_BYTES["list_tick_per_uav_with_partner"] * p
             out["roofline_collision"] = {

@@ -267,8 +267,9 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out);
 int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_rebuilds);
 
 /* how the collision ticks of mrs_swarm_tick_n / step + handle_collisions were evaluated: by the following step launch (fused), how often
- * a launch found the neighbour lists stale (a UAV had left its skin) and how many queued launches had to be issued again after it */
-int mrs_swarm_get_fused_stats(mrs_swarm_t* s, int64_t* fused_launches, int64_t* stalls, int64_t* replayed_launches);
+ * a launch found the neighbour lists stale (a UAV had left its skin), how many queued launches had to be issued again after it, and
+ * how many searches the host queued ahead of time (a UAV close to the edge of its skin) so that no launch found them stale */
+int mrs_swarm_get_fused_stats(mrs_swarm_t* s, int64_t* fused_launches, int64_t* stalls, int64_t* replayed_launches, int64_t* searches_ahead);
 
 /* diagnostic hook: the eight control words of the collision pass's neighbour-list state machine (skin flags of the two tick
  * parities, search counter, table-dirty flags, list-overflow counter — collide.hip); synchronises the stream.  tools/collision_words.py */

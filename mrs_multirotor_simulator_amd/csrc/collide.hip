@@ -32,6 +32,7 @@
 // the pass in rebuild mode.  Results are identical to searching every tick.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "swarm_layout.h"
@@ -46,6 +47,9 @@ constexpr double SKIN          = 0.5;         // neighbour lists: how far apart 
 constexpr double INV_CELL_WIDE = 1.0 / 2.25;  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508
 constexpr double LIST_R2       = 4.9821;      // > (sqrt(3) + SKIN)^2 = 4.98205...
 constexpr double POS_LIMIT     = MRS_POS_LIMIT;  // |coordinate| beyond this (or non-finite) never collides here
+// fused evaluation: a UAV beyond this fraction of the distance that invalidates the lists makes the host queue the next search in
+// stream order (no stall, no replay); the remaining 25 % (6 cm) are ten ticks at 6 m/s — more than the host runs ahead of the device
+static const double WARN_FRACTION = getenv("MRS_WARN_FRACTION") ? atof(getenv("MRS_WARN_FRACTION")) : 0.75;
 constexpr int    LIST_CAP      = 24;          // listed neighbours per UAV (0.7 expected at 64 m^3 per UAV, 4.6 at 10 m^3: P(> 24) ~ 1e-11;
                                               // with 8, one UAV in 10^4 overflowed at 30 m^3 per UAV and kept a 100 k swarm searching)
 
@@ -229,8 +233,10 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
 template <bool LISTS>
 __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
                               int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
-                              double rebounce, Pos4* pos_now) {
+                              double rebounce, Pos4* pos_now, const uint32_t* stall_word) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // a search queued ahead of time (swarm_host.hip: collide_in_stream) behind launches that have turned into no-ops does nothing either
+  if (LISTS && stall_word && *stall_word != 0u) return;
   if (LISTS) {
     // issued before the control words are looked at: on a list tick (the common case) these are the first links of the
     // dependent load chain, and the addresses are valid on a rebuild tick too
@@ -461,8 +467,10 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
 template <bool LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
-                                              double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id) {
+                                              double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id,
+                                              uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau) {
   (void)table_id;  // kept in the signature next to the insert kernels' one
+  if (LISTS && stall_word && *stall_word != 0u && *stall_word != stall_tau) return;  // (see k_pack_insert; an overflow of this very pass lets the rest of it finish)
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
   __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag
@@ -583,6 +591,10 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
       ctl[cur ^ 1] = 1u;
       atomicAdd(&ctl[6], 1u);  // statistics: lanes over the list capacity
       cnt = 0;
+      if (stall_word) {  // a search queued in stream order: the fused launches behind it must not use the incomplete lists
+        *stall_word = stall_tau;
+        __hip_atomic_store(&hostw[CTL_STALL], stall_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     if (active) {
       uint32_t prev = 0;
@@ -744,11 +756,11 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   w->cur ^= 1;
   if (rec_is_local_scratch)
     hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0,
-                       nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr);
+                       nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
   else
     hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
   hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
-                     rebounce, nullptr, 0, 1, nullptr, nullptr, 0);
+                     rebounce, nullptr, 0, 1, nullptr, nullptr, 0, nullptr, nullptr, 0u);
   return hipGetLastError();
 }
 
@@ -769,7 +781,10 @@ extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st,
   return hipStreamSynchronize(st);
 }
 
-extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st) {
+// guard_tau != 0: the pass is queued in stream order behind fused step launches (tick index of the last one = guard_tau): it does
+// nothing if those have stalled, and stalls what follows if the new lists come out incomplete
+extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, unsigned guard_tau,
+                                            hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork*    w = *work;
   const long long n = sw.n;
@@ -798,9 +813,9 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
   hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur]);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur], guard_tau ? w->fctl + CTL_STALL : nullptr);
   hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
-                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
+                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, guard_tau ? w->fctl + CTL_STALL : nullptr, w->hostw, guard_tau);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
   w->lists_live = true;
   w->g_lists_live = false;
@@ -847,7 +862,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
                      w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce);
   hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
-                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid);
+                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, nullptr, nullptr, 0u);
   w->fcur ^= 1;
   w->g_lists_live = true;
   w->lists_live   = false;  // the local-mode skin hook of the step kernel is off
@@ -868,6 +883,7 @@ extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, 
   cd->hostw    = w->hostw;
   cd->rebounce = rebounce;
   cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  cd->lim2_warn = cd->lim2 * (WARN_FRACTION * WARN_FRACTION);
   cd->tau      = tau;
   cd->n        = sw->n;
   cd->eval     = eval;
@@ -887,6 +903,7 @@ extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st) {
   CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * 2, st));
   w->hostw[CTL_STALL]    = 0u;
   w->hostw[CTL_PROGRESS] = 0u;
+  w->hostw[CTL_WARN]     = 0u;
   return hipSuccess;
 }
 
@@ -977,7 +994,8 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
   me.mass = P.mass; me.arm_length = P.arm_length; me.prop_radius = P.prop_radius;
   double f[3];
   bool   crashed;
-  mrs_list_eval(cd, i, me, cd.nbr_cnt[i], cd.nbr[i], f, crashed);
+  const uint32_t cnt = cd.nbr_cnt[i];
+  mrs_list_eval(cd, i, me, cnt, mrs_partner_record_flat(cd, cnt ? cd.nbr[i] : (uint32_t)i), f, crashed);
   sw.S[(size_t)(F_FEXT + 0) * np + i] = f[0];
   sw.S[(size_t)(F_FEXT + 1) * np + i] = f[1];
   sw.S[(size_t)(F_FEXT + 2) * np + i] = f[2];
@@ -1070,6 +1088,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->exp_slot = w->exp_slot;
   cd->rebounce = rebounce;
   cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  cd->lim2_warn = cd->lim2;  // (no ahead-of-time searches on this path: a search is a collective decision)
   cd->tau      = tau;
   cd->n        = sw->n;
   cd->eval     = eval;

@@ -36,7 +36,8 @@ extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hip
 struct CollideWork;
 extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                       int crash, double rebounce, int rec_is_local_scratch, hipStream_t st);
-extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, hipStream_t st);
+extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int crash, double rebounce, int force_rebuild, unsigned guard_tau,
+                                            hipStream_t st);
 extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                                      int crash, double rebounce, int force_rebuild, hipStream_t st);
 extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, hipStream_t st);
@@ -325,7 +326,8 @@ struct mrs_swarm {
   // by settle() when the host looks at the swarm first.  `log` holds the launches the device has not confirmed yet: when a UAV
   // leaves its skin during step T the launches after T turn into no-ops, and the host repeats the search and replays them.
   struct Collide { bool on = false; int enabled = 0, crash = 0; double rebounce = 0.0; };
-  struct TickRec { double dt; Collide eval; };  // one fused launch: the collision tick it evaluates first, then makeStep(dt)
+  // one fused launch: the collision tick it evaluates first (searched: a search queued right before it has done that), then makeStep(dt)
+  struct TickRec { double dt; Collide eval; bool searched; };
   Collide              pend;                        // requested after the most recent step, not evaluated yet
   bool                 collide_since_step = false;  // ... or evaluated already: either way the next step keeps the fused form
   bool                 p_valid = false;             // the position records hold the positions after the most recent step
@@ -334,7 +336,9 @@ struct mrs_swarm {
   std::vector<TickRec> log;
   uint32_t             tau = 0;                     // tick index of the last fused launch since the stream was last drained
   bool                 use_fused = true;            // tuning: MRS_FUSED_COLLISIONS=0 launches every collision tick on its own
-  int                  fused_lead = 8;              // launches the host may run ahead of the device (MRS_FUSED_LEAD)
+  int                  fused_lead = 4;              // launches the host may run ahead of the device (MRS_FUSED_LEAD)
+  uint32_t             search_mark = 0;             // tick index behind which the last ahead-of-time search was queued
+  int64_t              n_ahead_searches = 0;
   int64_t              n_stalls = 0, n_noop_launches = 0, n_fused = 0;
   // profiling
   int  profiling = 0;  // 0 off, 1 one event pair around the whole step_n/tick_n region, 2 one pair per step launch
@@ -1025,7 +1029,7 @@ static int finish_profile(mrs_swarm* s) {
 static int collide_now(mrs_swarm* s, const mrs_swarm::Collide& c, bool force) {
   int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
   if (rc) return rc;
-  HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, c.crash, c.rebounce, (force || s->nbr_dirty) ? 1 : 0, s->stream));
+  HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, c.crash, c.rebounce, (force || s->nbr_dirty) ? 1 : 0, 0u, s->stream));
   s->nbr_dirty = false;
   // the host must know whether the lists are complete before a step kernel may evaluate a tick from them
   unsigned w[8];
@@ -1052,7 +1056,7 @@ static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
   }
   CollDev cd;
   SwarmDev v = s->view();
-  HIPCHK(mrs_collide_fused_dev(&v, s->cwork, s->tau + 1, e.eval.on ? 1 : 0, e.eval.crash, e.eval.rebounce, &cd));
+  HIPCHK(mrs_collide_fused_dev(&v, s->cwork, s->tau + 1, (e.eval.on && !e.searched) ? 1 : 0, e.eval.crash, e.eval.rebounce, &cd));
   const int variant = s->n_cascade > 0 ? 0 : 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   s->region_launches++;
@@ -1092,6 +1096,7 @@ static int drain(mrs_swarm* s) {
     if (T == 0u || T > s->log.size()) {
       s->log.clear();
       s->tau = 0;
+      s->search_mark = 0;
       if (T) return fail(MRS_ERR_HIP, "collision lists: stall index beyond the launch log");
       HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));  // (progress word back to 0 with tau)
       return MRS_OK;
@@ -1099,8 +1104,10 @@ static int drain(mrs_swarm* s) {
     s->n_stalls++;
     s->n_noop_launches += (int64_t)s->log.size() - T;
     std::vector<mrs_swarm::TickRec> tail(s->log.begin() + T, s->log.end());
+    for (auto& e : tail) e.searched = false;  // (a search queued ahead of time behind the stalled launch did nothing)
     s->log.clear();
     s->tau = 0;
+    s->search_mark = 0;
     HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));
     // the collision tick that followed step T: the first replayed launch was going to evaluate it, or it is the pending one
     mrs_swarm::Collide& c = tail.empty() ? s->pend : tail[0].eval;
@@ -1149,7 +1156,16 @@ static int step_one(mrs_swarm* s, double dt) {
     if (hw && hw[CTL_STALL] != 0u && (rc = drain(s))) return rc;  // seen without synchronising: stop feeding no-ops
     if (s->pend.on && !fused_usable(s) && (rc = settle(s))) return rc;  // first tick / after host writes: the pass on its own
     if (fused_usable(s)) {
-      mrs_swarm::TickRec e{dt, s->pend};
+      mrs_swarm::TickRec e{dt, s->pend, false};
+      if (s->pend.on && hw && hw[CTL_WARN] > s->search_mark) {
+        // some UAV has used up most of its skin: repeat the search NOW, in stream order — it evaluates the pending collision tick
+        // itself — instead of running into the stall a few ticks on (no synchronisation, nothing to replay)
+        if ((rc = upload_types(s, dt))) return rc;
+        HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, s->pend.crash, s->pend.rebounce, 1, s->tau, s->stream));  // (tau >= 1: the warning came from a launch of this log)
+        e.searched     = true;
+        s->search_mark = s->tau;
+        s->n_ahead_searches++;
+      }
       s->pend.on            = false;
       s->collide_since_step = false;
       return launch_fused(s, e);
@@ -1968,12 +1984,13 @@ int mrs_swarm_get_collision_stats(mrs_swarm_t* s, int64_t* n_ticks, int64_t* n_r
   return MRS_OK;
 }
 
-int mrs_swarm_get_fused_stats(mrs_swarm_t* s, int64_t* fused_launches, int64_t* stalls, int64_t* replayed_launches) {
+int mrs_swarm_get_fused_stats(mrs_swarm_t* s, int64_t* fused_launches, int64_t* stalls, int64_t* replayed_launches, int64_t* searches_ahead) {
   MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
   if (fused_launches) *fused_launches = s->n_fused;
   if (stalls) *stalls = s->n_stalls;
   if (replayed_launches) *replayed_launches = s->n_noop_launches;
+  if (searches_ahead) *searches_ahead = s->n_ahead_searches;
   return MRS_OK;
 }
 

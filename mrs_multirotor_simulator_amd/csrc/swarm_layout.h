@@ -111,6 +111,8 @@ enum {
   CTL_OVERFLOW = 2,  // UAVs with more than LIST_CAP listed neighbours at the last search
   CTL_BADSLOT = 3,   // export-set translation: foreign neighbours that their owner does not export (must stay 0: the relation is symmetric)
   CTL_EXPORTS = 4,   // export-set search: number of own UAVs that some other rank lists
+  CTL_WARN = 5,      // tick index of the last launch in which some UAV was beyond the WARNING part of its skin: the host schedules the
+                     // next search ahead of time, in stream order, instead of waiting for the stall (host mirror only)
   CTL_WORDS = 8
 };
 
@@ -127,7 +129,7 @@ struct CollDev {
   const PartnerConst* g_const;  // [world * (1 + cap)] airframe constants of the exported UAVs (fixed between searches)
   Pos4*               send;     // [1 + cap] this rank's block of the next all-gather
   const uint32_t*     exp_slot; // [n] export slot of every own UAV (MRS_NO_SLOT: nobody else lists it)
-  double              rebounce, lim2;
+  double              rebounce, lim2, lim2_warn;
   uint32_t            tau;      // tick index of this launch (1, 2, ... since the host last drained the stream)
   int32_t             n, eval, crash, world, block;  // block = 1 + cap
 };

@@ -246,7 +246,7 @@ def load_library():
         "mrs_swarm_comm_init_loopback": [vp, vp, i32, C.c_int64],
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
-        "mrs_swarm_get_fused_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+        "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -402,10 +402,10 @@ class Swarm:
         return a.value, b.value
 
     def fused_stats(self):
-        """(collision ticks evaluated by the following step launch, stale-list stalls, launches replayed after a stall)"""
-        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
-        _check(_lib.mrs_swarm_get_fused_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        """(collision ticks evaluated by the following step launch, stale-list stalls, launches replayed after a stall, searches queued ahead of time)"""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _check(_lib.mrs_swarm_get_fused_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def set_profiling(self, enabled):
         _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))

@@ -593,10 +593,11 @@ def test_neighbour_lists_are_reused_and_rebuilt_with_identical_results(M, oracle
     if os.environ.get("MRS_NEIGHBOUR_LISTS", "1") != "0":  # (the tuning switch that searches on every tick)
         assert 3 <= rebuilds <= 100, f"{rebuilds} neighbour searches in {ticks} ticks"
         if os.environ.get("MRS_FUSED_COLLISIONS", "1") != "0":
-            fused, stalls, replayed = p.g.fused_stats()
-            # all but the ticks that searched were evaluated inside the next step launch; every search between two calls was a stall
-            assert fused >= ticks - rebuilds - 6 and 1 <= stalls <= rebuilds, (fused, stalls, replayed, rebuilds)
-            print(f"{ticks} ticks: {fused} fused, {rebuilds} searches, {stalls} stalls, {replayed} launches replayed")
+            fused, stalls, replayed, ahead = p.g.fused_stats()
+            # all but the ticks that searched were evaluated inside the next step launch; the searches were queued ahead of time
+            # (a UAV near the edge of its skin) or followed a stall (a UAV over the edge before the host had reacted)
+            assert fused >= ticks - rebuilds - 6 and stalls + ahead >= rebuilds - 6 and ahead >= 1, (fused, stalls, replayed, ahead, rebuilds)
+            print(f"{ticks} ticks: {fused} fused launches, {rebuilds} searches ({ahead} queued ahead, {stalls} after a stall), {replayed} launches replayed")
 
 
 def test_neighbour_lists_follow_host_writes(M, oracle):
