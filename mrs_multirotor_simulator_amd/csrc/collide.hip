@@ -995,7 +995,9 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
   double f[3];
   bool   crashed;
   const uint32_t cnt = cd.nbr_cnt[i];
-  mrs_list_eval(cd, i, me, cnt, mrs_partner_record_flat(cd, cnt ? cd.nbr[i] : (uint32_t)i), f, crashed);
+  double         ox, oy, oz, om, oa, op;
+  mrs_partner_flat(cd, cnt ? cd.nbr[i] : (uint32_t)i, ox, oy, oz, om, oa, op);
+  mrs_list_eval(cd, i, me.x, me.y, me.z, me.mass, me.arm_length, me.prop_radius, cnt, ox, oy, oz, om, oa, op, f, crashed);
   sw.S[(size_t)(F_FEXT + 0) * np + i] = f[0];
   sw.S[(size_t)(F_FEXT + 1) * np + i] = f[1];
   sw.S[(size_t)(F_FEXT + 2) * np + i] = f[2];
