@@ -281,6 +281,29 @@ int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8);
 int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int32_t n_steps, const double* params, const double* err,
                             const double* dt, const double* event, const double* new_sat, double* out);
 
+/* ONE component of the path for the UAVs [first, first + count), on each UAV's own state (x, v, R, omega, motor_rpm, external force),
+ * airframe / controller constants and PID state — the device functions the step kernels are made of, run on their own.  Row k of `in`
+ * (in_stride doubles) is the input for UAV first + k, row k of `out` receives the result; the PID-bearing controllers update the
+ * UAV's PID state like getControlSignal() mutates the reference's controller objects.  Backs the stand-alone L0 classes of the
+ * header facade (MultirotorModel, the controllers) and the per-component parity tests.  Matrices row-major.
+ *   component                        in                               out                             reference
+ *   MRS_COMP_REORTH                  R[9]                             R * L^-1 [9]                    multirotor_model.hpp:249-253, :314-316
+ *   MRS_COMP_MODEL_RHS               x[3] v[3] R[9] omega[3]          derivative, same order [18]     MultirotorModel::operator() :301-366
+ *   MRS_COMP_MIXER                   roll pitch yaw throttle          motors[8]                       Mixer::getControlSignal mixer.hpp:107-144
+ *   MRS_COMP_POSITION                position ref[3]                  velocity[3]                     position_controller.hpp:73-86
+ *   MRS_COMP_VELOCITY                velocity ref[3]                  acceleration[3]                 velocity_controller.hpp:68-102
+ *   MRS_COMP_ACCELERATION_HDG        acceleration[3] heading          Rd[9] throttle                  acceleration_controller.hpp:44-97
+ *   MRS_COMP_ACCELERATION_HDG_RATE   acceleration[3] heading_rate     tilt[3] heading_rate throttle   acceleration_controller.hpp:103-122
+ *   MRS_COMP_ATTITUDE                Rd[9] throttle                   rate[3] throttle                attitude_controller.hpp:79-100
+ *   MRS_COMP_TILT_HDG_RATE           tilt[3] heading_rate throttle    rate[3] throttle                attitude_controller.hpp:106-145
+ *   MRS_COMP_RATE                    rate[3] throttle                 roll pitch yaw throttle         rate_controller.hpp:67-81 */
+enum {
+  MRS_COMP_REORTH = 1, MRS_COMP_MODEL_RHS, MRS_COMP_MIXER, MRS_COMP_POSITION, MRS_COMP_VELOCITY, MRS_COMP_ACCELERATION_HDG,
+  MRS_COMP_ACCELERATION_HDG_RATE, MRS_COMP_ATTITUDE, MRS_COMP_TILT_HDG_RATE, MRS_COMP_RATE
+};
+int mrs_swarm_debug_component(mrs_swarm_t* s, int32_t component, int32_t first, int32_t count, const double* in, int32_t in_stride, double* out,
+                              int32_t out_stride, double dt);
+
 /* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
  * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
  * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */

@@ -235,8 +235,7 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
                               int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
                               double rebounce, Pos4* pos_now, const uint32_t* stall_word) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // a search queued ahead of time (swarm_host.hip: collide_in_stream) behind launches that have turned into no-ops does nothing either
-  if (LISTS && stall_word && *stall_word != 0u) return;
+  (void)stall_word;  // (the pass always runs in full: the two head tables are wiped alternately, a skipped pass would leave stale chains)
   if (LISTS) {
     // issued before the control words are looked at: on a list tick (the common case) these are the first links of the
     // dependent load chain, and the addresses are valid on a rebuild tick too
@@ -470,7 +469,10 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
                                               double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id,
                                               uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau) {
   (void)table_id;  // kept in the signature next to the insert kernels' one
-  if (LISTS && stall_word && *stall_word != 0u && *stall_word != stall_tau) return;  // (see k_pack_insert; an overflow of this very pass lets the rest of it finish)
+  // A search queued ahead of time (swarm_host.hip) behind fused launches that have turned into no-ops — their lists went stale at
+  // an earlier tick — builds its lists as usual (the table protocol stays in step) but must not latch forces or crash flags: the
+  // host repeats the search for the tick that stalled, with that tick's own parameters.
+  const bool muted = LISTS && stall_word && *stall_word != 0u;
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
   __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag
@@ -613,7 +615,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 #ifdef MRS_QUERY_CLOCK  // timing build (tools/query_phases.py): the force columns carry phase durations in 10-ns ticks
   fx = (double)(tA - t0); fy = (double)(tB - tA); fz = (double)(tC - tB);
 #endif
-  if (active) {
+  if (active && !muted) {
     sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
     sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
     sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;

@@ -30,6 +30,8 @@ extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int subste
 extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, int cascade, int blk0, int nblk, int with_mixed, hipStream_t st);
 extern "C" hipError_t mrs_launch_pid_probe_literal(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
 extern "C" hipError_t mrs_launch_pid_probe_fast(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
+extern "C" hipError_t mrs_launch_component_probe_literal(SwarmDev, int, int, int, const double*, int, double*, int, double, hipStream_t);
+extern "C" hipError_t mrs_launch_component_probe_fast(SwarmDev, int, int, int, const double*, int, double*, int, double, hipStream_t);
 // collide.hip
 extern "C" hipError_t mrs_launch_flags_update(uint32_t* F, int first, int count, uint32_t and_mask, uint32_t or_mask, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hipStream_t st);
@@ -2017,6 +2019,33 @@ int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int
   if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("pid probe: ") + hipGetErrorString(e));
+  return MRS_OK;
+}
+
+int mrs_swarm_debug_component(mrs_swarm_t* s, int32_t component, int32_t first, int32_t count, const double* in, int32_t in_stride, double* out,
+                              int32_t out_stride, double dt) {
+  MRS_ENTER(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  static const int in_w[11]  = {0, 9, 18, 4, 3, 3, 4, 4, 10, 5, 4};
+  static const int out_w[11] = {0, 9, 18, 8, 3, 3, 10, 5, 4, 4, 4};
+  if (component < MRS_COMP_REORTH || component > MRS_COMP_RATE) return fail(MRS_ERR_ARG, "unknown component");
+  if (!in || !out || in_stride < in_w[component] || out_stride < out_w[component] || !(dt > 0)) return fail(MRS_ERR_ARG, "bad component arguments");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  double*      d   = nullptr;
+  const size_t nin = (size_t)count * in_stride, nout = (size_t)count * out_stride;
+  HIPCHK(hipMalloc(&d, sizeof(double) * (nin + nout)));
+  hipError_t e = hipMemcpyAsync(d, in, sizeof(double) * nin, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d + nin, 0, sizeof(double) * nout, s->stream);
+  if (e == hipSuccess)
+    e = s->arith == MRS_ARITH_FAST ? mrs_launch_component_probe_fast(s->view(), component, first, count, d, in_stride, d + nin, out_stride, dt, s->stream)
+                                   : mrs_launch_component_probe_literal(s->view(), component, first, count, d, in_stride, d + nin, out_stride, dt, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d + nin, sizeof(double) * nout, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("component probe: ") + hipGetErrorString(e));
   return MRS_OK;
 }
 

@@ -68,6 +68,10 @@ class CommInfo(C.Structure):
 
 
 EXCHANGE_NONE, EXCHANGE_FULL_GATHER, EXCHANGE_EXPORT_SETS = 0, 1, 2
+# mrs_swarm_debug_component: component id -> (input width, output width)
+(COMP_REORTH, COMP_MODEL_RHS, COMP_MIXER, COMP_POSITION, COMP_VELOCITY, COMP_ACCELERATION_HDG, COMP_ACCELERATION_HDG_RATE, COMP_ATTITUDE,
+ COMP_TILT_HDG_RATE, COMP_RATE) = range(1, 11)
+COMP_WIDTHS = {1: (9, 9), 2: (18, 18), 3: (4, 8), 4: (3, 3), 5: (3, 3), 6: (4, 10), 7: (4, 5), 8: (10, 4), 9: (5, 4), 10: (4, 4)}
 
 
 EXCHANGE_NAMES = {0: "none", 1: "full all-gather of 48-B records per tick", 2: "export-set all-gather (boundary UAVs only), full gather on search ticks"}
@@ -91,7 +95,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
-    "mrs_slab_partition", "mrs_swarm_get_fused_stats",
+    "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -247,6 +251,7 @@ def load_library():
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
+        "mrs_swarm_debug_component": [vp, i32, i32, i32, dp, i32, dp, i32, f64],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -406,6 +411,14 @@ class Swarm:
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         _check(_lib.mrs_swarm_get_fused_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
+
+    def debug_component(self, component, first, count, rows, dt=0.001):
+        """one component of the path (COMP_*) for UAVs [first, first + count) on their own state; rows: (count, input width)"""
+        wi, wo = COMP_WIDTHS[component]
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(count, wi)
+        out = np.zeros((count, wo))
+        _check(_lib.mrs_swarm_debug_component(self._h, int(component), int(first), int(count), _dp(rows), wi, _dp(out), wo, float(dt)))
+        return out
 
     def set_profiling(self, enabled):
         _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))

@@ -51,6 +51,7 @@ class Diag(C.Structure):
                                           "nan_rollback")]
 
 
+COMP_WIDTHS = {1: (9, 9), 2: (18, 18), 3: (4, 8), 4: (3, 3), 5: (3, 3), 6: (4, 10), 7: (4, 5), 8: (10, 4), 9: (5, 4), 10: (4, 4)}
 OUTPUT_DTYPE = np.dtype([("position", "f8", 3), ("orientation", "f8", 4), ("velocity_body", "f8", 3),
                          ("angular_velocity", "f8", 3), ("linear_acceleration", "f8", 3), ("range", "f8")])
 
@@ -127,6 +128,7 @@ def lib():
         L.orc_swarm_timeout_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.orc_swarm_set_mass.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
         L.orc_swarm_set_ground_z.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
+        L.orc_swarm_debug_component.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_double]
         L.orc_pid_update.restype = C.c_double
         L.orc_pid_update.argtypes = [C.c_double] * 5 + [dp, dp, C.c_double, C.c_double]
         L.orc_llt_reorth.argtypes = [dp, dp]
@@ -286,6 +288,13 @@ class OracleSwarm:
         count = self.n - first if count is None else count
         out = np.zeros(count, dtype=OUTPUT_DTYPE)
         lib().orc_swarm_get_outputs(self._h, first, count, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def debug_component(self, component, first, count, rows, dt=0.001):
+        wi, wo = COMP_WIDTHS[component]
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(count, wi)
+        out = np.zeros((count, wo))
+        lib().orc_swarm_debug_component(self._h, int(component), int(first), int(count), _dp(rows), wi, _dp(out), wo, float(dt))
         return out
 
     def get_diag(self):

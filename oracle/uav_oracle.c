@@ -911,6 +911,86 @@ static void uav_make_step(uav_t* u, double dt, orc_diag_t* diag) {
   model_step(u, dt, diag);
 }
 
+/* One component of the path on UAV state — the counterpart of mrs_swarm_debug_component (include/mrs_swarm.h: same component
+ * ids, same row layouts, matrices row-major).  Each case sets the inputs the reference's function reads, calls exactly that
+ * function of this file, and returns what it wrote. */
+static void debug_component_one(uav_t* u, int comp, const double* a, double* o, double dt, orc_diag_t* diag) {
+  switch (comp) {
+    case 1: orc_llt_reorth(a, o); break; /* R * inverse(matrixL(LLT(R^T R))) */
+    case 2: {                            /* MultirotorModel::operator(): internal order x v Rcol0 Rcol1 Rcol2 w (:204-214) */
+      double y[18], k[18];
+      for (int i = 0; i < 3; i++) {
+        y[i] = a[i];
+        y[3 + i] = a[3 + i];
+        y[6 + i] = a[6 + 3 * i + 0];
+        y[9 + i] = a[6 + 3 * i + 1];
+        y[12 + i] = a[6 + 3 * i + 2];
+        y[15 + i] = a[15 + i];
+      }
+      model_rhs(u, y, k);
+      for (int i = 0; i < 3; i++) {
+        o[i] = k[i];
+        o[3 + i] = k[3 + i];
+        o[6 + 3 * i + 0] = k[6 + i];
+        o[6 + 3 * i + 1] = k[9 + i];
+        o[6 + 3 * i + 2] = k[12 + i];
+        o[15 + i] = k[15 + i];
+      }
+    } break;
+    case 3:
+      memcpy(u->control_group, a, 4 * sizeof(double));
+      mixer(u);
+      for (int m = 0; m < ORC_MAX_MOTORS; m++) o[m] = m < u->p.n_motors ? u->actuators[m] : 0.0;
+      break;
+    case 4:
+      memcpy(u->pos, a, 3 * sizeof(double));
+      position_controller(u, dt);
+      memcpy(o, u->vel_h, 3 * sizeof(double));
+      break;
+    case 5: velocity_controller(u, a, o, dt); break;
+    case 6:
+      memcpy(u->acc_h, a, 3 * sizeof(double));
+      u->acc_h_heading = a[3];
+      acceleration_controller_hdg(u);
+      memcpy(o, u->attitude_R, 9 * sizeof(double));
+      o[9] = u->attitude_throttle;
+      break;
+    case 7:
+      memcpy(u->acc_hr, a, 3 * sizeof(double));
+      u->acc_hr_rate = a[3];
+      acceleration_controller_hdg_rate(u);
+      memcpy(o, u->tilt, 3 * sizeof(double));
+      o[3] = u->tilt_heading_rate;
+      o[4] = u->tilt_throttle;
+      break;
+    case 8:
+      memcpy(u->attitude_R, a, 9 * sizeof(double));
+      u->attitude_throttle = a[9];
+      attitude_controller_att(u, dt);
+      memcpy(o, u->attitude_rate, 4 * sizeof(double));
+      break;
+    case 9:
+      memcpy(u->tilt, a, 3 * sizeof(double));
+      u->tilt_heading_rate = a[3];
+      u->tilt_throttle     = a[4];
+      attitude_controller_tilt(u, dt, diag);
+      memcpy(o, u->attitude_rate, 4 * sizeof(double));
+      break;
+    case 10:
+      memcpy(u->attitude_rate, a, 4 * sizeof(double));
+      rate_controller(u, dt);
+      memcpy(o, u->control_group, 4 * sizeof(double));
+      break;
+    default: break;
+  }
+}
+
+void orc_swarm_debug_component(orc_swarm_t* s, int32_t component, int32_t first, int32_t count, const double* in, int32_t in_stride, double* out,
+                               int32_t out_stride, double dt) {
+  for (int k = 0; k < count; k++)
+    debug_component_one(&s->u[first + k], component, in + (size_t)k * in_stride, out + (size_t)k * out_stride, dt, &s->diag);
+}
+
 /* ------------------------------------------------------------------ */
 /* swarm API                                                            */
 /* ------------------------------------------------------------------ */

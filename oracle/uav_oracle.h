@@ -163,6 +163,9 @@ void orc_swarm_set_ground_z(orc_swarm_t* s, int32_t first, int32_t count, double
 void orc_swarm_get_outputs(const orc_swarm_t* s, int32_t first, int32_t count, orc_uav_output_t* out);
 
 /* building blocks exposed for known-answer tests */
+/* one component of the path on the state of UAVs [first, first + count): ids and row layouts of mrs_swarm_debug_component */
+void orc_swarm_debug_component(orc_swarm_t* s, int32_t component, int32_t first, int32_t count, const double* in, int32_t in_stride, double* out,
+                               int32_t out_stride, double dt);
 double orc_pid_update(double kp, double kd, double ki, double saturation, double antiwindup,
                       double* last_error, double* integral, double error, double dt);   /* pid.hpp:67-96 */
 void   orc_llt_reorth(const double R[9], double out[9]);  /* R * inverse(matrixL(LLT(R^T R))), multirotor_model.hpp:249-253 */

@@ -1,13 +1,14 @@
 set -x
 mkdir -p gpurun_out/r2e
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r2e/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
-tail -5 gpurun_out/r2e/gpu_tests.log
-timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll.json 2> gpurun_out/r2e/bench_coll.err; echo "bench rc=$?"
-MRS_WARN_FRACTION=0.85 timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_w85.json 2> gpurun_out/r2e/bench_coll_w85.err; echo "bench rc=$?"
-MRS_WARN_FRACTION=0.6 timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_w60.json 2> gpurun_out/r2e/bench_coll_w60.err; echo "bench rc=$?"
-MRS_FUSED_LEAD=2 timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_lead2.json 2> gpurun_out/r2e/bench_coll_lead2.err; echo "bench rc=$?"
-MRS_FUSED_LEAD=8 timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_lead8.json 2> gpurun_out/r2e/bench_coll_lead8.err; echo "bench rc=$?"
-timeout -k 10 300 python bench.py --no-cpu-baseline --workload position+collisions --uavs 50000 > gpurun_out/r2e/bench_coll_50k.json 2> gpurun_out/r2e/bench_coll_50k.err; echo "bench rc=$?"
+timeout -k 10 150 python -m pytest "tests/test_parity_gpu.py::test_neighbour_lists_are_reused_and_rebuilt_with_identical_results" tests/test_random_sequences_gpu.py -x -q -m gpu -s > gpurun_out/r2e/risky.log 2>&1 || { echo "risky tests failed rc=$?"; tail -30 gpurun_out/r2e/risky.log; exit 1; }
+tail -3 gpurun_out/r2e/risky.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2e/gpu_tests.log 2>&1 || { echo "gpu tests failed rc=$?"; tail -30 gpurun_out/r2e/gpu_tests.log; exit 1; }
+tail -3 gpurun_out/r2e/gpu_tests.log
+for v in "" "MRS_WARN_FRACTION=0.85" "MRS_WARN_FRACTION=0.6" "MRS_FUSED_LEAD=2" "MRS_FUSED_LEAD=8"; do
+  tag=$(echo "$v" | tr -c 'A-Za-z0-9\n' '_')
+  env $v timeout -k 10 200 python bench.py --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_$tag.json 2> gpurun_out/r2e/bench_coll_$tag.err && echo "bench $v ok"
+done
+timeout -k 10 200 python bench.py --no-cpu-baseline --workload position+collisions --uavs 50000 > gpurun_out/r2e/bench_coll_50k.json 2> gpurun_out/r2e/bench_coll_50k.err && echo ok
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2e/trace_coll -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_trace.json 2> gpurun_out/r2e/trace_coll.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2e/trace_coll -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --workload position+collisions > gpurun_out/r2e/bench_coll_trace.json 2> gpurun_out/r2e/trace_coll.err
 f=$(find gpurun_out/r2e/trace_coll -name "*kernel_stats.csv" | head -1); cat $f | cut -c1-160
