@@ -15,12 +15,14 @@
 #define UAV_SYSTEM_H
 
 #include <memory>
+#include <stdexcept>
 #include <utility>
 #include <array>
 #include <vector>
 
 #include "multirotor_model.hpp"
 
+#include "controllers/pid.hpp"
 #include "controllers/mixer.hpp"
 #include "controllers/rate_controller.hpp"
 #include "controllers/attitude_controller.hpp"
@@ -49,7 +51,13 @@ public:
     POSITION_CMD,
   };
 
-  void makeStep(const double dt) {  // uav_system.hpp:304
+  // uav_system.hpp:304.  On an owning UavSystem (a swarm of one) this is the reference call.  On a view of a larger swarm
+  // (UavSwarm::Ref) it is refused: the reference's loop `for (i) uavs_[i]->makeStep(dt)` (src/multirotor_simulator.cpp:211-213)
+  // would otherwise step the WHOLE swarm once per UAV — call UavSwarm::makeStep(dt) once instead.
+  void makeStep(const double dt) {
+    int32_t n = 0;
+    mrs_throw_on_error(mrs_swarm_size(s_, &n));
+    if (n != 1) throw std::logic_error("UavSwarm::Ref::makeStep steps every UAV of the swarm: call UavSwarm::makeStep(dt) once per tick instead");
     mrs_throw_on_error(mrs_swarm_step(s_, dt));
   }
 
@@ -200,7 +208,7 @@ private:
 // ------------------------------------------------------------------------------------------------------------------
 class UavSwarm {
 public:
-  class Ref : public UavSystemApi {  // view of one UAV; makeStep() on a view steps the WHOLE swarm — prefer UavSwarm::makeStep
+  class Ref : public UavSystemApi {  // view of one UAV (non-owning); makeStep() is refused on it, see UavSystemApi::makeStep
   public:
     Ref(mrs_swarm_t* s, int i) : UavSystemApi(s, i) {}
   };
@@ -209,6 +217,7 @@ public:
     mrs_throw_on_error(mrs_swarm_create(n_uavs, device_id, &s_));
     mrs_throw_on_error(mrs_swarm_set_arith(s_, fast_arithmetic ? MRS_ARITH_FAST : MRS_ARITH_LITERAL));
   }
+  explicit UavSwarm(mrs_swarm_t* adopt) : s_(adopt) {}  // takes ownership of a library swarm (e.g. mrs_swarm_clone)
   ~UavSwarm() { mrs_swarm_destroy(s_); }
   UavSwarm(const UavSwarm&) = delete;
   UavSwarm& operator=(const UavSwarm&) = delete;
@@ -255,6 +264,23 @@ public:
     mrs_throw_on_error(mrs_swarm_tick_sharded_n(s_, dt, n_ticks, enabled, crash, rebounce));
   }
   void commDestroy() { mrs_throw_on_error(mrs_swarm_comm_destroy(s_)); }
+  // MRS_EXCHANGE_EXPORT_SETS (default: boundary UAVs only between two neighbour searches) or MRS_EXCHANGE_FULL_GATHER
+  void setExchange(int exchange) { mrs_throw_on_error(mrs_swarm_set_exchange(s_, exchange)); }
+  mrs_comm_info_t commInfo() {
+    mrs_comm_info_t ci;
+    mrs_throw_on_error(mrs_swarm_comm_info(s_, &ci));
+    return ci;
+  }
+  // spatially coherent shards for a swarm addressed by public index: order[k] = public index at position k of the x-sorted order;
+  // rank r of `world` holds order[lo_r, hi_r) with equal-count ranges (the first n % world ranks one more)
+  static std::vector<int64_t> slabPartition(const std::vector<Eigen::Vector3d>& pos, int world) {
+    std::vector<double> p(pos.size() * 3);
+    for (size_t k = 0; k < pos.size(); k++)
+      for (int j = 0; j < 3; j++) p[k * 3 + (size_t)j] = pos[k](j);
+    std::vector<int64_t> order(pos.size());
+    mrs_throw_on_error(mrs_slab_partition(p.data(), (int64_t)pos.size(), world, order.data()));
+    return order;
+  }
   void synchronize() { mrs_throw_on_error(mrs_swarm_synchronize(s_)); }
   // collision ticks so far, and how many of them had to repeat the neighbour search
   std::pair<int64_t, int64_t> collisionStats() {
@@ -327,7 +353,23 @@ public:
     mrs_throw_on_error(mrs_swarm_construct(s_, 0, 1, &c, p, &spawn_heading));
   }
 
-  // the reference object is copy-assignable; here ownership of the device state moves (uav_system_ = UavSystem(...) works)
+  // the reference object is a copy-assignable value (uav_system_ = UavSystem(...), src/uav_system_ros.cpp:105): a copy is an
+  // independent UAV with the same state, command, feed-forwards, PIDs and parameters (mrs_swarm_clone); moves hand the device state over
+  UavSystem(const UavSystem& o) : UavSystemApi(nullptr, 0) {
+    mrs_swarm_t* c = nullptr;
+    mrs_throw_on_error(mrs_swarm_clone(o.s_, &c));
+    own_ = std::make_unique<UavSwarm>(c);
+    s_   = c;
+  }
+  UavSystem& operator=(const UavSystem& o) {
+    if (this != &o) {
+      mrs_swarm_t* c = nullptr;
+      mrs_throw_on_error(mrs_swarm_clone(o.s_, &c));
+      own_ = std::make_unique<UavSwarm>(c);
+      s_   = c;
+    }
+    return *this;
+  }
   UavSystem(UavSystem&& o) noexcept : UavSystemApi(o.s_, 0), own_(std::move(o.own_)) { o.s_ = nullptr; }
   UavSystem& operator=(UavSystem&& o) noexcept {
     own_ = std::move(o.own_);

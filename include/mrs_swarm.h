@@ -187,6 +187,13 @@ int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x,
 /* MultirotorModel::setState — multirotor_model.hpp:424-433 (v_prev untouched, like the reference) */
 int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
                         const double* omega, const double* motor_rpm);
+/* MultirotorModel::setStatePos — multirotor_model.hpp:439-446: x, R = AngleAxis(-heading, z) and _initial_pos_; everything else stays */
+int mrs_swarm_set_state_pos(mrs_swarm_t* s, int32_t first, int32_t count, const double* pos, const double* heading);
+/* the controllers' PID state (layout of mrs_swarm_get_pid): the reference has no accessor for it — needed to copy a UavSystem */
+int mrs_swarm_set_pid(mrs_swarm_t* s, int32_t first, int32_t count, const double* pid);
+/* an independent copy of the whole swarm on the same device: state, commands, feed-forwards, PIDs, parameters, flags.  The
+ * reference's UavSystem is a copy-assignable value (src/uav_system_ros.cpp:105); collision bookkeeping starts afresh in the copy. */
+int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out);
 /* UavSystem::getImuAcceleration — uav_system.hpp:424 */
 int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu);
 /* MultirotorModel::getExternalForce — multirotor_model.hpp:452 */
@@ -281,6 +288,11 @@ int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8);
 int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int32_t n_steps, const double* params, const double* err,
                             const double* dt, const double* event, const double* new_sat, double* out);
 
+/* one PIDController::update (controllers/pid.hpp:67-96) for each of n independent controllers, on the GPU, with caller-held state:
+ * params = n x {kp, kd, ki, saturation, antiwindup}, state = n x {last_error, integral} (updated in place), err / dt / out = n.
+ * Backs the stand-alone PIDController class of the header facade. */
+int mrs_debug_pid_update(int32_t device_id, int32_t arith, int32_t n, const double* params, double* state, const double* err, const double* dt,
+                         double* out);
 /* ONE component of the path for the UAVs [first, first + count), on each UAV's own state (x, v, R, omega, motor_rpm, external force),
  * airframe / controller constants and PID state — the device functions the step kernels are made of, run on their own.  Row k of `in`
  * (in_stride doubles) is the input for UAV first + k, row k of `out` receives the result; the PID-bearing controllers update the

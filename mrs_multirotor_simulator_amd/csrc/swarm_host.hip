@@ -30,6 +30,8 @@ extern "C" hipError_t mrs_launch_step_literal(SwarmDev sw, double dt, int subste
 extern "C" hipError_t mrs_launch_step_fast(SwarmDev sw, double dt, int substeps, int cascade, int blk0, int nblk, int with_mixed, hipStream_t st);
 extern "C" hipError_t mrs_launch_pid_probe_literal(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
 extern "C" hipError_t mrs_launch_pid_probe_fast(const double*, const double*, const double*, const double*, const double*, double*, int, int, hipStream_t);
+extern "C" hipError_t mrs_launch_pid_update_probe_literal(const double*, double*, const double*, const double*, double*, int, hipStream_t);
+extern "C" hipError_t mrs_launch_pid_update_probe_fast(const double*, double*, const double*, const double*, double*, int, hipStream_t);
 extern "C" hipError_t mrs_launch_component_probe_literal(SwarmDev, int, int, int, const double*, int, double*, int, double, hipStream_t);
 extern "C" hipError_t mrs_launch_component_probe_fast(SwarmDev, int, int, int, const double*, int, double*, int, double, hipStream_t);
 // collide.hip
@@ -652,6 +654,13 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (device_id >= ndev) return fail(MRS_ERR_ARG, "device_id out of range");
   HIPCHK(hipSetDevice(device_id));
   mrs_swarm* s = new mrs_swarm();
+  // any failure below hands the half-built object (streams, events, device buffers) back through mrs_swarm_destroy
+  struct Guard {
+    mrs_swarm* p;
+    ~Guard() {
+      if (p) mrs_swarm_destroy(p);
+    }
+  } guard{s};
   s->n         = n_uavs;
   s->npad      = ((n_uavs + 63) / 64) * 64;
   if (const char* e = getenv("MRS_NEIGHBOUR_LISTS")) s->use_lists = atoi(e) != 0;
@@ -680,18 +689,20 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   HIPCHK(hipMemsetAsync(s->dDiag, 0, sizeof(unsigned long long) * 4, s->stream));
   s->uav_type.assign((size_t)s->npad, 0);
   s->uav_mode.assign((size_t)s->npad, (uint8_t)MRS_INPUT_UNKNOWN);
-  *out = s;
   if (n_uavs > 0) {
     int rc = mrs_swarm_construct(s, 0, n_uavs, nullptr, nullptr, nullptr);
     if (rc != MRS_OK) return rc;
   }
+  guard.p = nullptr;
+  *out    = s;
   return MRS_OK;
 }
 
 int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (!s) return MRS_OK;
   (void)hipSetDevice(s->device);
-  (void)hipStreamSynchronize(s->stream);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->stream2) (void)hipStreamSynchronize(s->stream2);
   for (auto e : s->ev) (void)hipEventDestroy(e);
   mrs_collide_free(s->cwork);
   if (s->dRec) (void)hipFree(s->dRec);
@@ -702,9 +713,9 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
-  (void)hipFree(s->dDiag);
-  (void)hipFree(s->dF);
-  (void)hipFree(s->dS);
+  if (s->dDiag) (void)hipFree(s->dDiag);
+  if (s->dF) (void)hipFree(s->dF);
+  if (s->dS) (void)hipFree(s->dS);
   if (s->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->rccl_comm);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
@@ -713,7 +724,7 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
-  (void)hipStreamDestroy(s->stream);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return MRS_OK;
 }
@@ -1819,6 +1830,68 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
   return MRS_OK;
 }
 
+int mrs_swarm_set_state_pos(mrs_swarm_t* s, int32_t first, int32_t count, const double* pos, const double* heading) {
+  MRS_ENTER(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!pos) return fail(MRS_ERR_ARG, "null position");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 3; j++)
+    if ((rc = put_strided(s, F_X + j, first, count, pos, 3, j))) return rc;
+  if ((rc = put_strided(s, F_INITZ, first, count, pos, 3, 2))) return rc;
+  std::vector<double> Rm((size_t)count * 9);
+  for (int k = 0; k < count; k++) angle_axis_z(-(heading ? heading[k] : 0.0), &Rm[(size_t)k * 9]);
+  for (int j = 0; j < 9; j++)
+    if ((rc = put_strided(s, F_R + j, first, count, Rm.data(), 9, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_set_pid(mrs_swarm_t* s, int32_t first, int32_t count, const double* pid) {
+  MRS_ENTER(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!pid) return fail(MRS_ERR_ARG, "null pid");
+  HIPCHK(hipSetDevice(s->device));
+  for (int j = 0; j < 24 && count > 0; j++)
+    if ((rc = put_strided(s, F_PID + j, first, count, pid, 24, j))) return rc;
+  return MRS_OK;
+}
+
+int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out) {
+  MRS_ENTER(s);
+  if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
+  *out = nullptr;
+  mrs_swarm* c = nullptr;
+  int rc = mrs_swarm_create(s->n, s->device, &c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipError_t e = hipMemcpyAsync(c->dS, s->dS, sizeof(double) * (size_t)F_COUNT * s->npad, hipMemcpyDeviceToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->dF, s->dF, sizeof(uint32_t) * (size_t)s->npad, hipMemcpyDeviceToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->dDiag, s->dDiag, sizeof(unsigned long long) * 4, hipMemcpyDeviceToDevice, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) {
+    mrs_swarm_destroy(c);
+    return fail(MRS_ERR_HIP, std::string("clone: ") + hipGetErrorString(e));
+  }
+  c->arith        = s->arith;
+  c->keys         = s->keys;
+  c->tparams      = s->tparams;
+  c->key_index    = s->key_index;
+  c->uav_type     = s->uav_type;
+  c->uav_mode     = s->uav_mode;
+  c->n_cascade    = s->n_cascade;
+  c->table_dt     = s->table_dt;
+  c->fext_active  = s->fext_active;
+  c->use_lists    = s->use_lists;
+  c->types_dirty  = true;  // the copy uploads its own type / block tables before its first launch
+  c->blocks_dirty = true;
+  c->nbr_dirty    = true;
+  *out = c;
+  return MRS_OK;
+}
+
 int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu) {
   MRS_ENTER(s);
   int rc = check_range(s, first, count);
@@ -2019,6 +2092,28 @@ int mrs_debug_pid_sequences(int32_t device_id, int32_t arith, int32_t n_seq, int
   if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("pid probe: ") + hipGetErrorString(e));
+  return MRS_OK;
+}
+
+int mrs_debug_pid_update(int32_t device_id, int32_t arith, int32_t n, const double* params, double* state, const double* err, const double* dt,
+                         double* out) {
+  if (n < 0 || !params || !state || !err || !dt || !out) return fail(MRS_ERR_ARG, "bad pid update arguments");
+  if (arith != MRS_ARITH_LITERAL && arith != MRS_ARITH_FAST) return fail(MRS_ERR_ARG, "unknown arithmetic flavour");
+  if (n == 0) return MRS_OK;
+  if (device_id >= 0) HIPCHK(hipSetDevice(device_id));
+  double* d = nullptr;  // params 5n | state 2n | err n | dt n | out n
+  HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n * 10));
+  double *dp = d, *ds = dp + (size_t)n * 5, *de = ds + (size_t)n * 2, *dd = de + n, *dout = dd + n;
+  hipError_t e = hipMemcpy(dp, params, sizeof(double) * (size_t)n * 5, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ds, state, sizeof(double) * (size_t)n * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(de, err, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dd, dt, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = arith == MRS_ARITH_FAST ? mrs_launch_pid_update_probe_fast(dp, ds, de, dd, dout, n, nullptr) : mrs_launch_pid_update_probe_literal(dp, ds, de, dd, dout, n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(state, ds, sizeof(double) * (size_t)n * 2, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("pid update: ") + hipGetErrorString(e));
   return MRS_OK;
 }
 

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_get_pid", "mrs_swarm_get_diag", "mrs_swarm_get_outputs", "mrs_swarm_timeout_input", "mrs_swarm_set_mass", "mrs_swarm_set_ground_z", "mrs_swarm_pack_positions", "mrs_swarm_pack_positions_to", "mrs_swarm_handle_collisions_gathered",
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
-    "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component",
+    "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component", "mrs_debug_pid_update", "mrs_swarm_set_state_pos", "mrs_swarm_set_pid", "mrs_swarm_clone",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -252,6 +252,10 @@ def load_library():
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
         "mrs_swarm_debug_component": [vp, i32, i32, i32, dp, i32, dp, i32, f64],
+        "mrs_debug_pid_update": [i32, i32, i32, dp, dp, dp, dp, dp],
+        "mrs_swarm_set_state_pos": [vp, i32, i32, dp, dp],
+        "mrs_swarm_set_pid": [vp, i32, i32, dp],
+        "mrs_swarm_clone": [vp, C.POINTER(vp)],
         "mrs_swarm_set_hold": [vp, i32, i32, i32],
         "mrs_swarm_get_outputs_view": [vp, i32, i32, C.POINTER(vp)],
         "mrs_swarm_input_staging": [vp, i32, i32, C.POINTER(dp)],
@@ -500,6 +504,21 @@ class Swarm:
 
     def get_pid(self, first=0, count=None):
         return self._get3(_lib.mrs_swarm_get_pid, first, count, 24)
+
+    def set_pid(self, first, count, pid):
+        _check(_lib.mrs_swarm_set_pid(self._h, first, count, _dp(_arr(pid, (count, 24)))))
+
+    def set_state_pos(self, first, count, pos, heading=None):
+        """MultirotorModel::setStatePos: position, R = AngleAxis(-heading, z) and the spawn height; nothing else changes"""
+        _check(_lib.mrs_swarm_set_state_pos(self._h, first, count, _dp(_arr(pos, (count, 3))), _dp(_arr(heading, (count,)))))
+
+    def clone(self):
+        """an independent copy of the swarm (mrs_swarm_clone)"""
+        other = object.__new__(Swarm)
+        other._h = C.c_void_p()
+        other.n = self.n
+        _check(_lib.mrs_swarm_clone(self._h, C.byref(other._h)))
+        return other
 
     def timeout_input(self, first, count):
         _check(_lib.mrs_swarm_timeout_input(self._h, first, count))
