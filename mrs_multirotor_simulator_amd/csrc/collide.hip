@@ -892,6 +892,7 @@ extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, 
   cd->crash    = crash;
   cd->world    = 1;
   cd->block    = 0;
+  cd->write_force = 0;  // the host re-derives the force when it is asked for (mrs_collide_latch_force)
   return hipSuccess;
 }
 extern "C" void mrs_collide_fused_advance(CollideWork* w) { w->pcur ^= 1; }
@@ -984,15 +985,23 @@ __global__ void k_export_translate(int n, long long n_max, int rank, long long m
 
 // handleCollisions of the tick after the most recent step, evaluated on its own from the lists (local partners: position records,
 // foreign partners: gathered export buffer — both current): the settle step at the end of a run of sharded ticks
+// own_from_records: the UAV's own position comes from the position records too (cd.p_in) and crash flags are left alone — the
+// force a fused launch evaluated but did not latch (CollDev::write_force == 0), re-derived from the very positions it used
+template <bool OWN_FROM_RECORDS>
 __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sw.n) return;
   const size_t      np = (size_t)sw.npad;
   const TypeParams& P  = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
   PosRecord         me;
-  me.x = sw.S[(size_t)(F_X + 0) * np + i];
-  me.y = sw.S[(size_t)(F_X + 1) * np + i];
-  me.z = sw.S[(size_t)(F_X + 2) * np + i];
+  if (OWN_FROM_RECORDS) {
+    const Pos4 pp = cd.p_in[i];
+    me.x = pp.x; me.y = pp.y; me.z = pp.z;
+  } else {
+    me.x = sw.S[(size_t)(F_X + 0) * np + i];
+    me.y = sw.S[(size_t)(F_X + 1) * np + i];
+    me.z = sw.S[(size_t)(F_X + 2) * np + i];
+  }
   me.mass = P.mass; me.arm_length = P.arm_length; me.prop_radius = P.prop_radius;
   double f[3];
   bool   crashed;
@@ -1003,7 +1012,7 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
   sw.S[(size_t)(F_FEXT + 0) * np + i] = f[0];
   sw.S[(size_t)(F_FEXT + 1) * np + i] = f[1];
   sw.S[(size_t)(F_FEXT + 2) * np + i] = f[2];
-  if (crashed) sw.F[i] |= FLAG_CRASHED;
+  if (crashed && !OWN_FROM_RECORDS) sw.F[i] |= FLAG_CRASHED;
 }
 
 // the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
@@ -1104,9 +1113,21 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
 
 extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st) {
   if (sw.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_list_eval_cd, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
+  hipLaunchKernelGGL(k_list_eval_cd<false>, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
   return hipGetLastError();
 }
+
+// the force of the collision tick a fused launch evaluated without latching it: same lists, same position records (index `pin`)
+extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int pin, int crash, double rebounce, hipStream_t st) {
+  if (sw.n <= 0 || !w || !w->P[0]) return hipSuccess;
+  CollDev cd;
+  memset(&cd, 0, sizeof cd);
+  cd.nbr = w->nbr; cd.nbr_cnt = w->nbr_cnt; cd.rec = w->rec_build; cd.p_in = w->P[pin & 1];
+  cd.rebounce = rebounce; cd.n = sw.n; cd.eval = 1; cd.crash = crash; cd.world = 1;
+  hipLaunchKernelGGL(k_list_eval_cd<true>, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
+  return hipGetLastError();
+}
+extern "C" int mrs_collide_fused_pin(const CollideWork* w) { return w ? w->pcur : 0; }
 
 extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, hipStream_t st) {
   hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->fctl, w->hostw);

@@ -67,6 +67,8 @@ extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, 
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
 extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st);
+extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int pin, int crash, double rebounce, hipStream_t st);
+extern "C" int        mrs_collide_fused_pin(const CollideWork* w);
 // outputs.hip
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count, hipStream_t st);
@@ -331,8 +333,13 @@ struct mrs_swarm {
   // leaves its skin during step T the launches after T turn into no-ops, and the host repeats the search and replays them.
   struct Collide { bool on = false; int enabled = 0, crash = 0; double rebounce = 0.0; };
   // one fused launch: the collision tick it evaluates first (searched: a search queued right before it has done that), then makeStep(dt)
-  struct TickRec { double dt; Collide eval; bool searched; };
+  struct TickRec { double dt; Collide eval; bool searched; int pin; };  // pin: which position buffer the launch read
   Collide              pend;                        // requested after the most recent step, not evaluated yet
+  // A fused launch consumes the force it evaluates from registers and does not write the F_ext columns (24 B per UAV and tick).
+  // While f_lazy.on those columns are stale: the latched force is "collision tick f_lazy on the position records f_lazy_pin",
+  // re-derived by settle() (or overwritten by the next search) before anything reads the columns.
+  Collide              f_lazy;
+  int                  f_lazy_pin = 0;
   bool                 collide_since_step = false;  // ... or evaluated already: either way the next step keeps the fused form
   bool                 p_valid = false;             // the position records hold the positions after the most recent step
   bool                 fk_ok   = false;             // the lists are complete (no UAV over the list capacity) and in local mode
@@ -1044,12 +1051,14 @@ static int collide_now(mrs_swarm* s, const mrs_swarm::Collide& c, bool force) {
   if (rc) return rc;
   HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, c.crash, c.rebounce, (force || s->nbr_dirty) ? 1 : 0, 0u, s->stream));
   s->nbr_dirty = false;
+  s->f_lazy.on = false;  // the pass latched this tick's force
+  s->p_valid = true;  // the pass refreshed the position records
+  if (!s->use_fused) return MRS_OK;  // (every tick on its own: nobody needs to know, the call stays asynchronous)
   // the host must know whether the lists are complete before a step kernel may evaluate a tick from them
   unsigned w[8];
   HIPCHK(mrs_collide_debug_words(s->cwork, s->stream, w));  // (synchronises the stream)
   s->fk_ok         = w[6] == s->last_overflow;  // no UAV over the list capacity in this pass
   s->last_overflow = w[6];
-  s->p_valid       = true;  // the pass refreshed the position records
   return MRS_OK;
 }
 
@@ -1089,10 +1098,19 @@ static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
   else
     HIPCHK(mrs_launch_step_coll_literal(v, cd, e.dt, variant, s->stream));
   if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
+  mrs_swarm::TickRec rec = e;
+  rec.pin = mrs_collide_fused_pin(s->cwork);
+  if (e.eval.on) {
+    s->f_lazy.on = !e.searched;  // (a search queued right before the launch latched the force itself)
+    if (!e.searched) {
+      s->f_lazy     = e.eval;
+      s->f_lazy_pin = rec.pin;
+    }
+  }
   mrs_collide_fused_advance(s->cwork);
   s->tau++;
   s->n_fused++;
-  s->log.push_back(e);
+  s->log.push_back(rec);
   if (e.eval.on) s->fext_active = true;
   return MRS_OK;
 }
@@ -1116,6 +1134,15 @@ static int drain(mrs_swarm* s) {
     }
     s->n_stalls++;
     s->n_noop_launches += (int64_t)s->log.size() - T;
+    {  // launch T was the last one that ran.  If it evaluated a collision tick, that force is the latched one (not written: see
+       // f_lazy); a launch without evaluation only ever follows a pass that wrote the columns
+      const mrs_swarm::TickRec& last = s->log[T - 1];
+      s->f_lazy.on = last.eval.on && !last.searched;
+      if (s->f_lazy.on) {
+        s->f_lazy     = last.eval;
+        s->f_lazy_pin = last.pin;
+      }
+    }
     std::vector<mrs_swarm::TickRec> tail(s->log.begin() + T, s->log.end());
     for (auto& e : tail) e.searched = false;  // (a search queued ahead of time behind the stalled launch did nothing)
     s->log.clear();
@@ -1149,7 +1176,7 @@ static int drain(mrs_swarm* s) {
 
 // everything the caller asked for so far has happened on the device (asynchronously at most the plain launches)
 static int settle(mrs_swarm* s) {
-  if (s->log.empty() && !s->pend.on) return MRS_OK;
+  if (s->log.empty() && !s->pend.on && !s->f_lazy.on) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
   int rc = drain(s);
   if (rc) return rc;
@@ -1157,6 +1184,10 @@ static int settle(mrs_swarm* s) {
     const mrs_swarm::Collide c = s->pend;
     s->pend.on = false;
     if ((rc = collide_now(s, c, false))) return rc;
+  } else if (s->f_lazy.on) {  // nothing newer overwrites the force the last fused launch evaluated: write it out now
+    if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+    HIPCHK(mrs_collide_latch_force(s->view(), s->cwork, s->f_lazy_pin, s->f_lazy.crash, s->f_lazy.rebounce, s->stream));
+    s->f_lazy.on = false;
   }
   return MRS_OK;
 }

@@ -132,4 +132,5 @@ struct CollDev {
   double              rebounce, lim2, lim2_warn;
   uint32_t            tau;      // tick index of this launch (1, 2, ... since the host last drained the stream)
   int32_t             n, eval, crash, world, block;  // block = 1 + cap
+  int32_t             write_force, _pad;             // latch the evaluated force in the F_ext columns as well
 };
