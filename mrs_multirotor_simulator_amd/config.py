@@ -74,21 +74,56 @@ def controller_params_from_config(cfg):
     return out
 
 
+_libc = None
+
+
+def randd(lo, hi):
+    """UavSystemRos::randd (src/uav_system_ros.cpp:653-658), quirks included: the span is floor(to - from) and the unit sample goes
+    through float; the C library generator, never seeded there (the same sequence as the C++ loader's, include/.../multirotor_simulator.hpp)."""
+    global _libc
+    import ctypes
+    import math
+
+    import numpy as np
+    if _libc is None:
+        _libc = ctypes.CDLL(None)
+        _libc.rand.restype = ctypes.c_int
+    zero_to_one = float(np.float32(_libc.rand())) / 2147483647.0  # RAND_MAX of glibc
+    return math.floor(hi - lo) * zero_to_one + lo
+
+
+def uav_spawns_from_config(cfg):
+    """[(name, type, x, y, z, heading)] as the UavSystemRos constructors see them: spawn randomisation (four randd draws per UAV, in
+    the order x, y, z, heading — src/uav_system_ros.cpp:89-94) applied when `randomization/enabled`."""
+    rnd = cfg.get("randomization", {}) or {}
+    out = []
+    for name in cfg["uav_names"]:
+        u = cfg[name]
+        sp = u["spawn"]
+        x, y, z, h = float(sp["x"]), float(sp["y"]), float(sp["z"]), float(sp["heading"])
+        if rnd.get("enabled", False):
+            b = rnd["bounds"]
+            x += randd(-float(b["x"]), float(b["x"]))
+            y += randd(-float(b["y"]), float(b["y"]))
+            z += randd(-float(b["z"]), float(b["z"]))
+            h += randd(-3.14, 3.14)
+        out.append((name, u["type"], x, y, z, h))
+    return out
+
+
 def spawn_swarm_from_config(cfg, device=-1, arith=_sw.ARITH_FAST):
     """The loop of MultirotorSimulator::onInit (src/multirotor_simulator.cpp:150-157) + the UavSystemRos constructor for
     every name in `uav_names`: returns (Swarm, names).  Ends with the two warm-up steps."""
     import numpy as np
-    names = list(cfg["uav_names"])
+    spawns = uav_spawns_from_config(cfg)
+    names = [sp[0] for sp in spawns]
     sw = _sw.Swarm(len(names), device=device, arith=arith)
     ctl = controller_params_from_config(cfg)
     cache = {}
-    for i, name in enumerate(names):
-        u = cfg[name]
-        ty = u["type"]
+    for i, (name, ty, x, y, z, heading) in enumerate(spawns):
         if ty not in cache:
             cache[ty] = model_params_from_config(cfg, ty)
-        sp = u["spawn"]
-        sw.construct(i, 1, cache[ty], [[float(sp["x"]), float(sp["y"]), float(sp["z"])]], [float(sp["heading"])])
+        sw.construct(i, 1, cache[ty], [[x, y, z]], [heading])
     n = len(names)
     sw.set_mixer_params(0, n, bool(ctl["mixer"]["desaturation"]))
     sw.set_rate_params(0, n, **ctl["rate_controller"])

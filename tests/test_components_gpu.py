@@ -66,7 +66,7 @@ def test_reorthonormalisation(mrs, oracle, fast):
         scale = np.maximum(np.abs(np.where(fin, o, 0)).max(axis=1, keepdims=True), 1.0)
         assert (np.abs(np.where(fin, g - o, 0)) / scale).max() < 1e-6
     Rh = o[:1000].reshape(-1, 3, 3)
-    assert np.abs(np.einsum("nij,nik->njk", Rh, Rh) - np.eye(3)).max() < 1e-5  # first-order orthonormalisation of a near-rotation
+    assert np.abs(np.einsum("nij,nik->njk", Rh, Rh) - np.eye(3)).max() < 3e-4  # R L^-1 only orthonormalises to first order (multirotor_model.hpp:249-253)
 
 
 @pytest.mark.parametrize("fast", [False, True])

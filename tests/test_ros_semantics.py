@@ -305,3 +305,28 @@ def test_cpp_config_loader_reads_the_400_uav_launch_layering(mrs):
     gx, gy = np.meshgrid(np.arange(20) * 4.0, np.arange(20) * 4.0, indexing="ij")
     want = np.stack([gx.ravel(), gy.ravel()], axis=1)
     assert sorted(map(tuple, xy - xy.min(axis=0))) == sorted(map(tuple, want))  # a 20 x 20 grid with 4 m pitch
+
+
+def test_python_loader_applies_spawn_randomisation_like_the_cpp_loader():
+    """`randomization/enabled` (src/uav_system_ros.cpp:89-94): four randd draws per UAV, floor(to - from) span and the float cast
+    included; the draws come from the C library generator like the C++ loader's (the Python loader used to ignore it)."""
+    import ctypes
+    import math
+    import os
+    from mrs_multirotor_simulator_amd import config
+    cfg = config.load_yaml_files([os.path.join(os.path.dirname(__file__), "golden", "sample_config.yaml")])
+    plain = config.uav_spawns_from_config(cfg)
+    cfg["randomization"] = {"enabled": True, "bounds": {"x": 2.5, "y": 1.0, "z": 0.7}}
+    libc = ctypes.CDLL(None)
+    libc.srand(1234)
+    got = config.uav_spawns_from_config(cfg)
+    libc.srand(1234)
+    libc.rand.restype = ctypes.c_int
+    for (n0, t0, x0, y0, z0, h0), (n1, t1, x1, y1, z1, h1) in zip(plain, got):
+        assert (n0, t0) == (n1, t1)
+        exp = []
+        for base, b in ((x0, 2.5), (y0, 1.0), (z0, 0.7), (h0, 3.14)):
+            u = float(np.float32(libc.rand())) / 2147483647.0
+            exp.append(base + (math.floor(2 * b) * u - b))  # floor(to - from): bounds 2.5 -> span 5, 1.0 -> 2, 0.7 -> 1 (!), 3.14 -> 6
+        assert (x1, y1, z1, h1) == tuple(exp)
+    assert any(abs(a[2] - b[2]) > 1e-3 for a, b in zip(plain, got))
