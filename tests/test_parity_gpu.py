@@ -296,6 +296,49 @@ def test_collision_neighbour_set_vs_reference_kdtree(M, oracle):
     helpers.assert_close(f, expect, 1e-13, "forces vs reference kd-tree neighbours")
 
 
+def test_collisions_three_body_clusters_in_the_reference_traversal_order(M, oracle):
+    """UAVs with THREE OR MORE partners: the reference adds the rebounce forces in the order its kd-tree hands the neighbours out
+    (src/multirotor_simulator.cpp:330-353), this library in ascending partner index.  The two sums differ by rounding only: held
+    here against forces accumulated in the reference's OWN traversal order (oracle/_ref: the reference's nanoflann, unsorted
+    results), at a few ulps of the force scale.  Mixed airframes so that the masses in the force expression differ."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(15)
+    n_clusters, per = 300, 5
+    n = n_clusters * per
+    centres = rng.uniform(0, 120, (n_clusters, 3)) + [0, 0, 10]
+    pos = (centres[:, None, :] + rng.normal(0, 0.22, (n_clusters, per, 3))).reshape(n, 3)  # five UAVs within ~0.5 m of each other
+    kinds = ["x500", "f450", "t650"]
+    p = Pair(M, n)
+    params = {}
+    for k in range(n):
+        a = kinds[k % 3]
+        params[k] = p.construct(k, 1, a, pos=pos[k:k + 1], heading=np.zeros(1))
+    p.both("handle_collisions", True, False, 100.0)
+    fg, fo = p.g.get_external_force(), p.o.get_external_force()
+    off, idx, d2 = oracle.ref_radius_neighbours(pos, 3.0, 10)
+    expect = np.zeros((n, 3))
+    multi = 0
+    for i in range(n):
+        hits = 0
+        for j, d in zip(idx[off[i]:off[i + 1]], d2[off[i]:off[i + 1]]):  # the reference's order, as returned
+            if j == i:
+                continue
+            pi, pj = params[i], params[int(j)]
+            if d < ((pi.arm_length + pi.prop_radius) + pj.arm_length) + pj.prop_radius:
+                rel = pos[i] - pos[j]
+                z = (rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2]
+                if z > 0:
+                    rel = rel / np.sqrt(z)
+                expect[i] += ((100.0 * rel) * pi.mass) * (pj.mass / (pi.mass + pj.mass))
+                hits += 1
+        multi += hits >= 3
+    assert multi > 200, "the scenario must hold many UAVs with three or more partners"
+    scale = np.abs(expect).max()
+    assert np.abs(fg - expect).max() <= 8 * np.finfo(float).eps * scale, "summation order: more than a few ulps"
+    helpers.assert_close(fg, fo, 1e-15, "GPU vs oracle (both ascending index)")
+
+
 def test_timer_main_tick_order(M, oracle):
     """tick_n == {makeStep for all; handleCollisions} repeated (src/multirotor_simulator.cpp:211-217): forces act next tick."""
     rng = np.random.default_rng(8)
