@@ -43,9 +43,13 @@ namespace {
 // cells are floor(pos * INV_CELL): any consistent assignment with an edge above the search radius works, and the multiply
 // avoids three ~70-cycle IEEE divisions per cell_of
 constexpr double INV_CELL      = 1.0 / 1.75;  // plain search: edge 1.75 m > sqrt(3.0) = 1.7320508
-constexpr double SKIN          = 0.5;         // neighbour lists: how far apart beyond sqrt(3) a listed pair may be
-constexpr double INV_CELL_WIDE = 1.0 / 2.25;  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508
-constexpr double LIST_R2       = 4.9821;      // > (sqrt(3) + SKIN)^2 = 4.98205...
+#ifndef MRS_SKIN
+#define MRS_SKIN 0.5  // (compile-time so that the cell arithmetic stays in constants; tools/variant_bench.sh sweeps it)
+#endif
+constexpr double SKIN          = MRS_SKIN;    // neighbour lists: how far apart beyond sqrt(3) a listed pair may be
+constexpr double SQRT3_UP      = 1.7320508075688775;                      // >= sqrt(3)
+constexpr double INV_CELL_WIDE = 1.0 / (SQRT3_UP + SKIN + 0.0179491924);  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508 (SKIN 0.5)
+constexpr double LIST_R2       = (SQRT3_UP + SKIN) * (SQRT3_UP + SKIN) * (1.0 + 1e-9) + 1e-5;  // > (sqrt(3) + SKIN)^2 (4.98206 at SKIN 0.5)
 constexpr double POS_LIMIT     = MRS_POS_LIMIT;  // |coordinate| beyond this (or non-finite) never collides here
 // fused evaluation: a UAV beyond this fraction of the distance that invalidates the lists makes the host queue the next search in
 // stream order (no stall, no replay); the remaining 25 % (6 cm) are ten ticks at 6 m/s — more than the host runs ahead of the device
@@ -207,7 +211,8 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
   double fx = 0.0, fy = 0.0, fz = 0.0;
   bool   crashed = false;
   {  // the position the partners of this UAV read in a following fused step + collision launch (step_device.inc *_coll)
-    const Pos4 pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i], 0.0};
+    const Pos4 pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i],
+                     (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};  // .w: airframe type (collide_device.inc)
     pos_now[i]    = pp;
   }
   if (cnt) {
@@ -269,7 +274,7 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   r.prop_radius = P.prop_radius;
   rec[i] = r;
   if (LISTS) {
-    const Pos4 pp = {r.x, r.y, r.z, 0.0};
+    const Pos4 pp = {r.x, r.y, r.z, (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};
     pos_now[i]    = pp;
   }
   insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
@@ -928,7 +933,8 @@ __global__ void k_fill_positions(SwarmDev sw, Pos4* pos_now) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sw.n) return;
   const size_t np = (size_t)sw.npad;
-  const Pos4   pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i], 0.0};
+  const Pos4   pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i],
+                     (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};
   pos_now[i]      = pp;
 }
 
