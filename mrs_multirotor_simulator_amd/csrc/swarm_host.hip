@@ -347,7 +347,7 @@ struct mrs_swarm {
   std::vector<TickRec> log;
   uint32_t             tau = 0;                     // tick index of the last fused launch since the stream was last drained
   bool                 use_fused = true;            // tuning: MRS_FUSED_COLLISIONS=0 launches every collision tick on its own
-  int                  fused_lead = 4;              // launches the host may run ahead of the device (MRS_FUSED_LEAD)
+  int                  fused_lead = 3;              // launches the host may run ahead of the device (MRS_FUSED_LEAD; 2-3 measured best, 8: stalls)
   uint32_t             search_mark = 0;             // tick index behind which the last ahead-of-time search was queued
   int64_t              n_ahead_searches = 0;
   int64_t              n_stalls = 0, n_noop_launches = 0, n_fused = 0;
