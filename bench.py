@@ -9,9 +9,10 @@ collisions (weak scaling: UAVs are independent, no data-path collective).  For N
 sub-record: BASELINE configs[4], 1 000 000 UAVs with mutual collisions sharded over the N ranks, the collision exchange over RCCL.
 Rank 0 prints ONE JSON line.
 
-Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced with MAX
-over ranks.  One region of the driver's K = 20 lasts 0.2 ms, a quarter of it host latency, so regions are repeated until 50 ms have
-been measured and `ms_per_step` / `value` come from the MEDIAN region (`regions`, `first_region_ms_per_step` are reported too).
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, repeated until 50 ms
+have been measured.  `ms_per_step` / `value` = the median region's DEVICE time (hipEvent pair on the swarm's stream around the region's
+launches, MAX over ranks): one region of the driver's K = 20 lasts 0.2 ms, a fifth of it host start-up and synchronize latency, which
+is not throughput.  The wall-clock figure of the same regions is in the line too (`wall_ms_per_step`, `value_wall_clock`).
 """
 import argparse
 import json
