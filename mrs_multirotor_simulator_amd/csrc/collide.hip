@@ -1023,14 +1023,21 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
 
 // the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
 // batch of ticks, whose last launch nobody has looked behind yet
-__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, uint32_t* fctl, volatile uint32_t* hostw) {
-  uint32_t stall = fctl[CTL_STALL];
+// progress_tau != 0: also stands in for the fused launch of a rank that holds no UAVs (it reports progress and the warning word)
+__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, uint32_t* fctl, volatile uint32_t* hostw, uint32_t progress_tau) {
+  uint32_t stall = fctl[CTL_STALL], warn = fctl[CTL_WARN];
   for (int q = 0; q < world; q++) {
-    const uint32_t h = (uint32_t)x_recv[(size_t)q * (size_t)block].w;
+    const Pos4     hd = x_recv[(size_t)q * (size_t)block];
+    const uint32_t h = (uint32_t)hd.w, wq = (uint32_t)hd.z;
     if (h != 0u && (stall == 0u || h < stall)) stall = h;
+    if (wq != 0u && (warn == 0u || wq < warn)) warn = wq;
   }
   fctl[CTL_STALL] = stall;
+  fctl[CTL_WARN]  = warn;
   __hip_atomic_store(&hostw[CTL_STALL], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&hostw[CTL_WARN], warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (progress_tau != 0u && (stall == 0u || progress_tau <= stall))
+    __hip_atomic_store(&hostw[CTL_PROGRESS], progress_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -1071,7 +1078,7 @@ extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? 
 extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st) {
   CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_WORDS, st));
   CK(hipMemsetAsync(map_send, 0xFF, sizeof(uint32_t) * (size_t)(n_max + 2), st));  // padding UAVs: no slot
-  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = 0u;
+  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = 0u;
   if (sw.n > 0) {
     hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl);
     hipLaunchKernelGGL(k_fill_positions, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur]);
@@ -1107,7 +1114,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->exp_slot = w->exp_slot;
   cd->rebounce = rebounce;
   cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
-  cd->lim2_warn = cd->lim2;  // (no ahead-of-time searches on this path: a search is a collective decision)
+  cd->lim2_warn = cd->lim2 * (WARN_FRACTION * WARN_FRACTION);  // the warning travels in the collective's headers (swarm_host.hip: export_ticks)
   cd->tau      = tau;
   cd->n        = sw->n;
   cd->eval     = eval;
@@ -1135,8 +1142,8 @@ extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int p
 }
 extern "C" int mrs_collide_fused_pin(const CollideWork* w) { return w ? w->pcur : 0; }
 
-extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, hipStream_t st) {
-  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->fctl, w->hostw);
+extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, unsigned progress_tau, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->fctl, w->hostw, progress_tau);
   return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, 
 extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w, long long my_offset, unsigned tau, int eval, int crash, double rebounce,
                                              CollDev* cd);
 extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st);
-extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, unsigned progress_tau, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void       mrs_collide_invalidate_gathered(CollideWork* w);
 extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
@@ -298,7 +298,6 @@ struct mrs_swarm {
   uint32_t* x_map_recv = nullptr;   // [world][2 + n_max]
   int64_t   x_export_count = 0;
   std::vector<unsigned> x_last_overflow;
-  int       x_batch = 16;           // ticks enqueued between two looks at the stall word (MRS_EXPORT_BATCH)
   int64_t   x_searches = 0, x_ticks = 0, x_noop_ticks = 0;
   double*   dS = nullptr;
   uint32_t* dF = nullptr;
@@ -1444,7 +1443,6 @@ int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   if (s->comm_n_max < 1) s->comm_n_max = 1;
   s->x_ok         = false;
   s->x_last_overflow.assign((size_t)world, 0u);
-  if (const char* e = getenv("MRS_EXPORT_BATCH")) s->x_batch = atoi(e) > 0 ? atoi(e) : 1;
   if (const char* e = getenv("MRS_EXCHANGE")) s->exchange = atoi(e) == 1 ? MRS_EXCHANGE_FULL_GATHER : MRS_EXCHANGE_EXPORT_SETS;
   HIPCHK(hipMalloc(&s->comm_send, sizeof(PosRecord) * (size_t)s->comm_n_max));
   HIPCHK(hipMalloc(&s->comm_recv, sizeof(PosRecord) * (size_t)s->comm_n_max * (size_t)world));
@@ -1680,18 +1678,29 @@ int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval)
     else
       HIPCHK(mrs_launch_step_coll_literal(v, cd, dt, variant, s->stream));
     mrs_collide_fused_advance(s->cwork);
+  } else {
+    HIPCHK(mrs_collide_export_fold_stall(s->cwork, s->tau + 1, s->stream));  // a rank without UAVs still watches the headers
   }
   s->tau++;
   const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
   return comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
 }
 
+// Ticks of the export-set exchange.  All ranks must issue the same launches and collectives in the same order, yet nobody may wait
+// for anybody on the host.  What keeps them in step: every decision is taken from words that reach all ranks with the positions
+// themselves (headers of the export collective, folded by each fused launch into pinned host words), at a launch index that is a
+// function of those words alone:
+//   * warning word W (tick in which some UAV of some rank had used 75 % of its skin): the search is done before launch W + D;
+//   * stall word T (some UAV left its skin during step T; launches > T are no-ops everywhere): the segment ends with launch T + L + 1;
+//   * L = launches a host may run ahead of its device (progress word), D = L + 3: a host deciding on launch W + D, or on T + L + 1,
+//     has provably seen W, or T (the launches that report them have completed on its device by then).
+// A segment ends with fold + synchronise (the only host wait), then the search where one is due.
 int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide& c) {
-  const volatile unsigned* hw;
   int  rc, done = 0;
   bool pending = false;  // the collision tick after the most recent step has not been evaluated yet
   s->p_valid = false;    // (single-GPU lazies do not mix with this path)
   s->fk_ok   = false;
+  const unsigned lead = (unsigned)(s->fused_lead > 0 ? s->fused_lead : 1), search_ahead = lead + 3;
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
       const int k = n_ticks - done < s->x_fallback_left ? n_ticks - done : s->x_fallback_left;
@@ -1700,39 +1709,48 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       done += k;
       continue;
     }
-    if (!s->x_ok) {  // no usable export lists (first tick, host writes, lists gone stale): this tick on the search path
+    if (!s->x_ok) {  // no usable export lists (first tick, lists gone stale): this tick on the search path
       if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
       int incomplete = 0;
       if ((rc = export_search(s, c, &incomplete))) return rc;
       s->collision_ticks++;
       s->x_ticks++;
       done++;
+      pending = false;
       if (incomplete) s->x_fallback_left = 64;
       continue;
     }
-    const int b = n_ticks - done < s->x_batch ? n_ticks - done : s->x_batch;
+    // ---- a segment of fused ticks ----
+    const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+    const unsigned first = s->tau + 1;                                 // launch indices run on from the last search
+    unsigned       last  = s->tau + (unsigned)(n_ticks - done);       // ... to the end of the call, unless a word says otherwise
     mrs_swarm::Collide off;
-    for (int t = 0; t < b; t++) {
+    while (s->tau < last) {
+      const unsigned next = s->tau + 1;
+      for (long spins = 0; (int)(next - hw[CTL_PROGRESS]) > (int)lead && hw[CTL_STALL] == 0u && spins < 2000000000L; spins++) __builtin_ia32_pause();
+      const unsigned T = hw[CTL_STALL], W = hw[CTL_WARN];
+      if (T != 0u && T + lead + 1 < last) last = T + lead + 1;
+      if (W != 0u && W + search_ahead - 1 < last) last = W + search_ahead - 1;
+      if (next > last) break;
       if ((rc = launch_fused_export(s, dt, pending ? c : off))) return rc;
       pending = true;
     }
-    HIPCHK(mrs_collide_export_fold_stall(s->cwork, s->stream));
+    HIPCHK(mrs_collide_export_fold_stall(s->cwork, 0u, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    hw = mrs_collide_host_words(s->cwork);
-    const unsigned T = hw[CTL_STALL];  // identical on every rank: the stall words travel in the headers of the collective
-    const int ran = (T == 0u || (int)T > b) ? b : (int)T;
-    done += ran;
+    const unsigned T = hw[CTL_STALL], W = hw[CTL_WARN];  // identical on every rank
+    const unsigned launched = s->tau + 1 - first;
+    const unsigned ran = (T != 0u && T + 1 >= first && T + 1 - first < launched) ? T + 1 - first : launched;
+    done += (int)ran;
     s->x_ticks += ran;
     s->collision_ticks += ran;
-    s->tau = 0;
-    if (T != 0u) {  // some UAV (of some rank) left its skin during step T: launches T+1.. of the batch did nothing
-      s->x_noop_ticks += b - ran;
+    s->x_noop_ticks += launched - ran;
+    if (T != 0u || (W != 0u && done < n_ticks)) {
+      // the lists are stale after step T / about to be: all ranks search on the state they have now, which also evaluates the
+      // collision tick that followed the last step that ran
       int incomplete = 0;
-      if ((rc = export_search(s, c, &incomplete))) return rc;  // evaluates the collision tick after step T
+      if ((rc = export_search(s, c, &incomplete))) return rc;
       pending = false;
       if (incomplete) s->x_fallback_left = 64;
-    } else {
-      HIPCHK(mrs_collide_fused_reset(s->cwork, s->stream));  // (progress word / tick numbering start over)
     }
   }
   if (pending && s->n > 0) {  // the last tick's handleCollisions: the export buffer holds the positions after the last step
