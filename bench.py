@@ -66,6 +66,41 @@ def pmc_traffic(args, n):
     return None, None
 
 
+def live_traffic(args):
+    """HBM-side bytes per dispatch of the step kernel, MEASURED in this run: two short child runs of the same workload under
+    `rocprofv3 --pmc` — FETCH_SIZE and WRITE_SIZE in separate passes, kernel-trace / stats off, as MI355X_MICROARCH.md prescribes —
+    corrected as the guide says (FETCH_SIZE x2 on gfx950, both x1024).  The children are ordinary child processes (`-- python
+    bench.py --pmc-child ...`, the program itself after `--`); any failure returns None and the committed profile is used instead."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mrs_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--uavs", str(args.uavs), "--workload", args.workload, "--arith", args.arith, "--substeps", str(args.substeps),
+               "--volume-per-uav", str(args.volume_per_uav), "--steps", "64", "--warmup", "16"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            acc = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                   if row["Counter_Name"] == ctr and row["Kernel_Name"].startswith("mrs_uav_")]
+            if not acc:
+                return None, f"no step-kernel rows for {ctr}"
+            vals[ctr] = sum(acc) / len(acc)
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            return None, f"rocprofv3 --pmc {ctr}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 64 steps"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +117,9 @@ def parse():
     ap.add_argument("--min-measure-ms", type=float, default=50.0, help="regions of --steps steps are repeated until this much was timed")
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
                     help="the 1 000 000-UAV collision leg (BASELINE configs[4]); auto = whenever N > 1")
+    ap.add_argument("--traffic", choices=["live", "profile", "off"], default="live",
+                    help="roofline.traffic: live = two rocprofv3 --pmc child runs of the same workload (N=1 only), profile = the committed summary")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run rocprofv3 wraps for --traffic live
     ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
     ap.add_argument("--config5-shards", choices=["slabs", "index"], default="slabs", help="x-sorted slabs (boundary sets stay small) or index ranges")
     ap.add_argument("--config5-exchange", choices=["export", "full"], default="export",
@@ -254,6 +292,11 @@ def headline_leg(args, R):
         sw.synchronize()
         torch.cuda.synchronize()
 
+    if args.pmc_child:  # under rocprofv3 --pmc: just run the launches
+        run(args.warmup)
+        run(args.steps)
+        sync_local()
+        return None
     sw.set_profiling(1)  # one hipEvent pair around every step_n / tick_n call, on the swarm's stream
     times, ev = timed_regions(R, run, sync_local, args.steps, args.warmup, args.min_measure_ms, after_region=sw.last_step_kernel_ms)
     sw.set_profiling(0)
@@ -274,7 +317,13 @@ def headline_leg(args, R):
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         moved = BYTES_MOVED_PER_UAV_STEP[key] * n / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args, n)
+        traffic, traffic_src = (None, None)
+        if args.traffic == "live" and world == 1:
+            traffic, traffic_src = live_traffic(args)
+            if traffic is None:
+                sys.stderr.write(f"bench.py: live PMC traffic unavailable ({traffic_src}); using the committed profile\n")
+        if traffic is None and args.traffic != "off":
+            traffic, traffic_src = pmc_traffic(args, n)
         # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
         # non-temporal accesses for model-only steps of small swarms
         npad = (n + 63) // 64 * 64
@@ -406,6 +455,9 @@ def main():
     if R.world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {R.world} rank(s)")
     out = headline_leg(args, R)
+    if args.pmc_child:
+        R.close()
+        return
     if args.config5 == "on" or (args.config5 == "auto" and R.world > 1):
         c5 = config5_leg(args, R)
         if R.rank == 0:
