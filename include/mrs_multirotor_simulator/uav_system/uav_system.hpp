@@ -263,6 +263,12 @@ public:
   void tickSharded(double dt, int n_ticks, bool enabled, bool crash, double rebounce) {
     mrs_throw_on_error(mrs_swarm_tick_sharded_n(s_, dt, n_ticks, enabled, crash, rebounce));
   }
+  // the same over an in-process group (several UavSwarm objects of one process, one host thread each: multi-device hosts without
+  // RCCL, virtual shards on one device) or over a caller-supplied all-gather (MPI, ...)
+  void commInitLoopback(mrs_loopback_group_t* group, int rank, int64_t n_total) { mrs_throw_on_error(mrs_swarm_comm_init_loopback(s_, group, rank, n_total)); }
+  void commInitCustom(int world, int rank, int64_t n_total, mrs_allgather_fn fn, void* user) {
+    mrs_throw_on_error(mrs_swarm_comm_init_custom(s_, world, rank, n_total, fn, user));
+  }
   void commDestroy() { mrs_throw_on_error(mrs_swarm_comm_destroy(s_)); }
   // MRS_EXCHANGE_EXPORT_SETS (default: boundary UAVs only between two neighbour searches) or MRS_EXCHANGE_FULL_GATHER
   void setExchange(int exchange) { mrs_throw_on_error(mrs_swarm_set_exchange(s_, exchange)); }

@@ -4,6 +4,8 @@
 // Exit code 0 and "ok ..." lines on success.
 #include <cmath>
 #include <cstdio>
+#include <memory>
+#include <thread>
 #include <mrs_multirotor_simulator/multirotor_simulator.hpp>
 
 using namespace mrs_multirotor_simulator;
@@ -76,5 +78,84 @@ int main() {
   CHECK(ya[2] < pos[0](2) - 0.1);
   a.commDestroy();
   std::printf("ok crash_and_destroy\n");
+
+  // ---- three shards of one swarm in this process (x-sorted slabs, public index kept through the permutation), one host thread each,
+  //      exchanging through an in-process loopback group: the export-set exchange from a plain C++ host ----
+  {
+    const int world = 3, m = 900;
+    std::vector<Eigen::Vector3d> p3;
+    for (int i = 0; i < m; i++) {  // a sheet of UAVs 1.9 m apart in x (collisions only inside the pairs below), slab faces cut through it
+      const int pair = i / 2;
+      p3.push_back(Eigen::Vector3d(1.9 * (pair % 30) + 0.55 * (i % 2), 2.5 * (pair / 30), 9.0 + 0.02 * (i % 5)));
+    }
+    const std::vector<int64_t> order = UavSwarm::slabPartition(p3, world);
+    UavSwarm whole(m, -1, false);
+    whole.construct(0, m, mp, p3, std::vector<double>((size_t)m, 0.0));
+    whole.warmUp();
+    mrs_loopback_group_t* group = nullptr;
+    CHECK(mrs_loopback_group_create(world, &group) == MRS_OK);
+    std::vector<std::unique_ptr<UavSwarm>> shard;
+    std::vector<std::vector<int64_t>>      own((size_t)world);
+    for (int r = 0; r < world; r++) {
+      const int64_t base = m / world, rem = m % world, lo = r * base + (r < rem ? r : rem), hi = lo + base + (r < rem ? 1 : 0);
+      std::vector<Eigen::Vector3d> pr;
+      for (int64_t k = lo; k < hi; k++) {
+        own[(size_t)r].push_back(order[(size_t)k]);
+        pr.push_back(p3[(size_t)order[(size_t)k]]);
+      }
+      shard.push_back(std::make_unique<UavSwarm>((int)(hi - lo), -1, false));
+      shard.back()->construct(0, (int)(hi - lo), mp, pr, std::vector<double>(pr.size(), 0.0));
+      shard.back()->warmUp();
+      shard.back()->commInitLoopback(group, r, m);
+    }
+    for (int i = 0; i < m; i++) {
+      reference::Position c;
+      c.position = Eigen::Vector3d(p3[(size_t)i](0) + 0.5, p3[(size_t)i](1), p3[(size_t)i](2) + 1.0);
+      whole[i].setInput(c);
+    }
+    for (int r = 0; r < world; r++)
+      for (size_t k = 0; k < own[(size_t)r].size(); k++) {
+        reference::Position c;
+        const auto&         q = p3[(size_t)own[(size_t)r][k]];
+        c.position = Eigen::Vector3d(q(0) + 0.5, q(1), q(2) + 1.0);
+        (*shard[(size_t)r])[(int)k].setInput(c);
+      }
+    whole.tick(0.001, 150, true, false, 100.0);
+    std::vector<std::thread> th;
+    std::vector<int>         failed((size_t)world, 0);
+    for (int r = 0; r < world; r++)
+      th.emplace_back([&, r] {
+        try {
+          shard[(size_t)r]->tickSharded(0.001, 150, true, false, 100.0);  // collective: every rank from its own thread
+        } catch (const std::exception& e) {
+          std::printf("rank %d: %s\n", r, e.what());
+          failed[(size_t)r] = 1;
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < world; r++) CHECK(!failed[(size_t)r]);
+    const std::vector<double> xw = whole.getPoses();
+    double                    worst3 = 0;
+    for (int r = 0; r < world; r++) {
+      const std::vector<double> xs = shard[(size_t)r]->getPoses();
+      for (size_t k = 0; k < own[(size_t)r].size(); k++)
+        for (int j = 0; j < 3; j++) {
+          const double ref = xw[(size_t)own[(size_t)r][k] * 3 + (size_t)j];
+          worst3           = std::fmax(worst3, std::fabs(xs[k * 3 + (size_t)j] - ref) / (1.0 + std::fabs(ref)));
+        }
+    }
+    const mrs_comm_info_t ci = shard[1]->commInfo();
+    std::printf("3 loopback shards vs one swarm: worst relative difference %.3e; rank 1 sends %lld B per tick (%lld on a search tick), %lld searches in %lld ticks\n",
+                worst3, (long long)ci.bytes_per_tick, (long long)ci.bytes_per_rebuild, (long long)ci.searches, (long long)ci.ticks);
+    CHECK(worst3 < 1e-12);
+    CHECK(ci.exchange == MRS_EXCHANGE_EXPORT_SETS && ci.ticks == 150 && ci.searches >= 1 && ci.searches < 60);
+    CHECK(ci.bytes_per_tick < ci.bytes_per_rebuild);
+    th.clear();
+    for (int r = 0; r < world; r++) th.emplace_back([&, r] { shard[(size_t)r]->commDestroy(); });
+    for (auto& t : th) t.join();
+    shard.clear();
+    CHECK(mrs_loopback_group_destroy(group) == MRS_OK);
+    std::printf("ok loopback_export_sets\n");
+  }
   return 0;
 }

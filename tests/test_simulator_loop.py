@@ -108,10 +108,11 @@ def test_sharded_tick_host_compiles(mrs):
 @pytest.mark.gpu
 def test_library_driven_sharded_tick_from_a_cpp_host(mrs):
     """mrs_swarm_comm_init / tick_sharded_n in a process without PyTorch: RCCL from the system loader path, one-rank communicator,
-    same results as the local ticks, crash mode, destroy."""
+    same results as the local ticks, crash mode, destroy; then three slab shards of one swarm on std::threads over a loopback group
+    (export-set exchange) against the whole swarm."""
     out = subprocess.run([_build_cpp(mrs, "sharded_tick_test")], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stdout + out.stderr
-    for tag in ("communicator", "sharded_ticks_equal_local_ticks", "crash_and_destroy"):
+    for tag in ("communicator", "sharded_ticks_equal_local_ticks", "crash_and_destroy", "loopback_export_sets"):
         assert f"ok {tag}" in out.stdout, out.stdout
 
 
