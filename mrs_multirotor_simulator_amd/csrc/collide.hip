@@ -324,9 +324,64 @@ __device__ __forceinline__ void list_tick_gathered(const SwarmDev& sw, const Pos
 
 // gathered records, lists on: list tick for the rank's own UAVs, or (rebuild) insert of ALL records + a copy of them as the
 // reference of the next skin tests
+// Bounding box of this rank's usable records, widened by the list radius: bb[0..2] lower, bb[3..5] upper corner.  Records of other
+// ranks outside it cannot be on any list of this rank, so a search inserts the own shard plus its halo instead of the whole swarm
+// (1/8 of the inserts and of the table's occupancy at eight slab shards).  Two small launches; they return at once on list ticks.
+constexpr int BBOX_BLOCKS = 128;
+__device__ __forceinline__ void bbox_reduce_block(double (&l)[3], double (&h)[3], double (*lo)[256], double (*hi)[256]) {
+  const int t = threadIdx.x;
+  for (int c = 0; c < 3; c++) {
+    lo[c][t] = l[c];
+    hi[c][t] = h[c];
+  }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s)
+      for (int c = 0; c < 3; c++) {
+        lo[c][t] = fmin(lo[c][t], lo[c][t + s]);
+        hi[c][t] = fmax(hi[c][t], hi[c][t + s]);
+      }
+    __syncthreads();
+  }
+}
+// stage 1: BBOX_BLOCKS partial boxes over the rank's own records
+__global__ void __launch_bounds__(256) k_own_bbox_part(const PosRecord* rec, long long my_offset, int n_own, double* part, const uint32_t* ctl, int cur,
+                                                       int force) {
+  __shared__ double lo[3][256], hi[3][256];
+  if (!force && ctl[cur] == 0u) return;  // a list tick: nobody searches
+  double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_own; i += BBOX_BLOCKS * 256) {
+    const PosRecord r = rec[my_offset + i];
+    if (!record_usable(r)) continue;
+    l[0] = fmin(l[0], r.x); l[1] = fmin(l[1], r.y); l[2] = fmin(l[2], r.z);
+    h[0] = fmax(h[0], r.x); h[1] = fmax(h[1], r.y); h[2] = fmax(h[2], r.z);
+  }
+  bbox_reduce_block(l, h, lo, hi);
+  if (threadIdx.x < 3) {
+    part[blockIdx.x * 6 + threadIdx.x]     = lo[threadIdx.x][0];
+    part[blockIdx.x * 6 + 3 + threadIdx.x] = hi[threadIdx.x][0];
+  }
+}
+// stage 2: the box, widened by `margin`
+__global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, double margin, double* bb, const uint32_t* ctl, int cur, int force) {
+  __shared__ double lo[3][256], hi[3][256];
+  if (!force && ctl[cur] == 0u) return;
+  double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+  if (threadIdx.x < BBOX_BLOCKS)
+    for (int c = 0; c < 3; c++) {
+      l[c] = part[threadIdx.x * 6 + c];
+      h[c] = part[threadIdx.x * 6 + 3 + c];
+    }
+  bbox_reduce_block(l, h, lo, hi);
+  if (threadIdx.x < 3) {
+    bb[threadIdx.x]     = lo[threadIdx.x][0] - margin;
+    bb[3 + threadIdx.x] = hi[threadIdx.x][0] + margin;
+  }
+}
+
 __global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRecord* rec_build, long long n_total, long long my_offset, uint32_t mask,
                                         uint2* head, uint2* next, uint32_t* ctl, int cur, int force, int table_id, uint2* head_to_clear,
-                                        uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash, double rebounce) {
+                                        uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash, double rebounce, const double* bb) {
   const long long j  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int       ic = j < sw.n ? (int)j : sw.n - 1;
   const uint32_t  cnt = nbr_cnt[ic], j0 = nbr[ic];
@@ -347,7 +402,10 @@ __global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRe
   if (j >= n_total) return;
   const PosRecord r = rec[j];
   rec_build[j]      = r;
-  insert_uav(j, cell_of<true>(r.x, r.y, r.z), mask, head, next);
+  Cell            c = cell_of<true>(r.x, r.y, r.z);
+  // outside this rank's widened bounding box: nobody here can list it (a comparison with NaN bounds — no usable own record — is false)
+  c.ok = c.ok && r.x >= bb[0] && r.y >= bb[1] && r.z >= bb[2] && r.x <= bb[3] && r.y <= bb[4] && r.z <= bb[5];
+  insert_uav(j, c, mask, head, next);
 }
 
 // The 27 bucket heads of a UAV's neighbourhood, filtered: .x != 0 marks an entry for the work list (a head of the probed cell,
@@ -640,6 +698,7 @@ struct CollideWork {
   uint32_t * nbr = nullptr, *nbr_cnt = nullptr, *ctl = nullptr;
   int        fcur = 0;             // which of ctl[0..1] the next tick reads
   bool       lists_live = false;   // rec_build / nbr describe this swarm as of some earlier tick
+  double*    g_bbox = nullptr;       // gathered mode: this rank's bounding box widened by the list radius (6 doubles)
   PosRecord* g_rec_build = nullptr;  // gathered mode: all records as of this rank's last rebuild
   long long  g_cap = 0;
   bool       g_lists_live = false;
@@ -662,6 +721,8 @@ struct CollideWork {
 static void free_work(CollideWork* w) {
   (void)hipFree(w->head[0]); (void)hipFree(w->head[1]); (void)hipFree(w->next);
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
+  (void)hipFree(w->g_bbox);
+  w->g_bbox = nullptr;
   (void)hipFree(w->exp_slot); (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
   w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
   w->exp_slot_cap = w->x_cap = 0;
@@ -865,9 +926,19 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   w->cur ^= 1;
   const unsigned gN = (unsigned)((n_total + 255) / 256);
   const double   lim2 = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
-  hipLaunchKernelGGL(k_skin_gathered, dim3(gN), dim3(256), 0, st, rec, w->g_rec_build, n_total, w->ctl, w->fcur, lim2);
+  if (!w->g_bbox) CK(hipMalloc(&w->g_bbox, sizeof(double) * 6 * (BBOX_BLOCKS + 1)));  // the box, then the partial boxes
+  if (force) {
+    // (the search is decided: the comparison of all records with those of the last search would only cost time — 14 us at 1 M records;
+    //  its other job, clearing the flag word the query may raise, is one memset)
+    CK(hipMemsetAsync(w->ctl + (w->fcur ^ 1), 0, sizeof(uint32_t), st));
+  } else {
+    hipLaunchKernelGGL(k_skin_gathered, dim3(gN), dim3(256), 0, st, rec, w->g_rec_build, n_total, w->ctl, w->fcur, lim2);
+  }
+  // (also on list ticks: the device may decide on a search)
+  hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, rec, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, force);
+  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN + 1e-6, w->g_bbox, w->ctl, w->fcur, force);
   hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->g_bbox);
   hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, nullptr, nullptr, 0u);
   w->fcur ^= 1;
