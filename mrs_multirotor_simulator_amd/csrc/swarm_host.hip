@@ -450,7 +450,9 @@ static int upload_blocks(mrs_swarm* s) {
         t = 0xFFFFu;
         break;
       }
-    s->block_type[(size_t)b] = (uint32_t)t | ((t == 0xFFFFu ? (uint32_t)MRS_MAX_MOTORS : (uint32_t)s->keys[t].mp.n_motors) << 16);
+    // (a block beyond the last UAV, or a swarm without UAVs, has no airframe type to look up)
+    const bool typed = t != 0xFFFFu && (size_t)t < s->keys.size();
+    s->block_type[(size_t)b] = (uint32_t)t | ((typed ? (uint32_t)s->keys[t].mp.n_motors : (uint32_t)MRS_MAX_MOTORS) << 16);
     if (t == 0xFFFFu) s->mixed_blocks.push_back(b);
   }
   HIPCHK(hipStreamSynchronize(s->stream));

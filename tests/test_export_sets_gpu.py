@@ -177,3 +177,33 @@ def test_export_sets_follow_host_writes_and_ragged_shards(mrs, oracle):
     for key in ("x", "v", "R", "omega", "motor_rpm"):
         helpers.assert_close(a[key], so[key], RTOL_LITERAL, key)
     vs.close()
+
+
+@pytest.mark.parametrize("world,n_total", [(3, 2), (4, 5), (2, 1)])
+def test_export_sets_with_empty_and_tiny_shards(mrs, oracle, world, n_total):
+    """more ranks than UAVs: a rank without UAVs still takes part in every collective and watches the headers"""
+    M = mrs
+    rng = np.random.default_rng(3)
+    pos = np.array([[0.0, 0.0, 10.0], [0.5, 0.1, 10.0], [0.2, 0.6, 10.1], [30.0, 0.0, 10.0], [30.4, 0.2, 10.0]])[:n_total]
+    st = helpers.random_state(rng, n_total, 4, tilted=True)
+    st["x"] = pos
+    st["v"] = rng.normal(0, 3.0, (n_total, 3))
+    cmd = rng.uniform(0.4, 0.55, (n_total, 4))
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    o = oracle.OracleSwarm(n_total)
+    o.construct(0, n_total, po, pos, np.zeros(n_total))
+    o.set_state(0, n_total, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, n_total, oracle.ACTUATOR_CMD, cmd)
+    order = M.slab_partition(pos, world)
+    vs = VirtualShards(M, world, order, helpers.to_product_params(M, po), pos, np.zeros(n_total), st, M.ACTUATOR_CMD, cmd, M.ARITH_LITERAL,
+                       M.EXCHANGE_EXPORT_SETS)
+    for n in (1, 40, 60):
+        vs.tick_n(n, True, False, 100.0)
+        for _ in range(n):
+            o.step(DT)
+            o.handle_collisions(True, False, 100.0)
+        a, so = vs.gather(), o.get_state()
+        helpers.assert_close(a["f"], o.get_external_force(), 1e-11, "forces")
+        for key in ("x", "v", "R", "omega", "motor_rpm"):
+            helpers.assert_close(a[key], so[key], RTOL_LITERAL, key)
+    vs.close()
