@@ -181,7 +181,13 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
 #ifndef MRS_TABLE_FACTOR
 #define MRS_TABLE_FACTOR 4
 #endif
-constexpr int      PAIR_CAP  = 1024;  // bucket heads taken into the LDS list per pass
+// bucket heads taken into the LDS list per pass.  Sized so that the list-building query keeps its LDS under 20 KB: eight one-wave
+// blocks per CU (what its 195 VGPRs allow), 2048 on the chip — the 1563 blocks of a 100 k swarm then run in ONE round.  With 1024
+// entries (24.6 KB, six blocks per CU = 1536) the last 27 blocks waited for a second round and the search took 56 us instead of 33.
+#ifndef MRS_PAIR_CAP
+#define MRS_PAIR_CAP 640
+#endif
+constexpr int      PAIR_CAP  = MRS_PAIR_CAP;
 constexpr int      HIT_CAP   = 6;
 constexpr uint32_t META_WALK = 0x10000u;  // pair meta: owner lane | probed cell q << 8 | WALK (follow the `next` link)
 
@@ -453,19 +459,21 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
   uint32_t*   hit_n;
   uint32_t*   nl_j;    // [64][LIST_CAP]
   uint32_t*   nl_n;
-  uint32_t*   more_flag;
+  uint32_t*   next_n;
   uint32_t*   hit_overflow;
 };
 
 // C: uniform sweeps over one window of the work list, U independent entries per lane and iteration so that their loads overlap.
-// A chained bucket is walked IN PLACE: after a member has been evaluated its slot takes the next member of the chain, and the
-// window is swept again until every chain has ended — no appends, so nothing can overflow.
+// A chained bucket is walked inside the list: after a member has been evaluated, the next member of its chain is written back —
+// COMPACTED to the front (slot k < the number of entries read so far, so no unread entry is overwritten) — and the shrunken
+// list is swept again until every chain has ended.  Never more entries than the sweep started with: nothing can overflow, and
+// the later levels of the walk (a few percent of the heads) cost one short pass each instead of a pass over every head.
 template <bool LISTS>
 __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int lane, const PosRecord* rec, const uint2* next, long long wave_first,
                                              int crash) {
   constexpr int U = 4;
-  for (bool more = true; more;) {
-    if (lane == 0) *L.more_flag = 0;
+  while (wn != 0u) {
+    if (lane == 0) *L.next_n = 0;  // entries of the next sweep
     __syncthreads();
     for (uint32_t base = 0; base < wn; base += 64 * U) {
       uint2    pe[U], nx[U];
@@ -491,17 +499,22 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
                     (long long)pe[u].x - 1 != wave_first + ow;  // idx == i, src/multirotor_simulator.cpp:335
         }
       }
+      // the candidates' records, requested together with the chain links above (one memory round trip per sweep, not two);
+      // unconditional loads from always-valid addresses, see load_heads
+      PosRecord ob[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) ob[u] = rec[live[u] ? (long long)pe[u].x - 1 : wave_first];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const uint32_t p = base + u * 64 + lane;
-        if (p < wn && pe[u].x != 0u) {  // the slot moves on to the next member of its chain (or ends)
-          L.pair_e[p] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
-          if (nx[u].x != 0u) *L.more_flag = 1u;
+        if (nx[u].x != 0u) {  // the chain goes on: its next member joins the next sweep
+          const uint32_t k = atomicAdd(L.next_n, 1u);
+          L.pair_e[k] = make_uint2(nx[u].x, nx[u].y & ~CHAIN_BIT);
+          L.pair_m[k] = pm[u];
         }
         if (!live[u]) continue;
         const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
         const int4      mc = L.me_cell[ow];
-        const PosRecord o  = rec[pe[u].x - 1u];
+        const PosRecord o  = ob[u];
         const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
         if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
         const PosRecord m = L.me_s[ow];
@@ -521,8 +534,8 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
       }
     }
     __syncthreads();
-    more = *L.more_flag != 0u;
-    __syncthreads();  // nobody resets the flag before everybody has read it
+    wn = *L.next_n;
+    __syncthreads();  // nobody resets the counter before everybody has read it
   }
 }
 
@@ -676,7 +689,12 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
     }
   }
 #ifdef MRS_QUERY_CLOCK  // timing build (tools/query_phases.py): the force columns carry phase durations in 10-ns ticks
+#if MRS_QUERY_CLOCK == 2
+  const unsigned long long tD = clock_fence(LISTS && active ? nbr_cnt[i] : 0u);
+  fx = (double)(tB - t0); fy = (double)(tC - tB); fz = (double)(tD - tC);
+#else
   fx = (double)(tA - t0); fy = (double)(tB - tA); fz = (double)(tC - tB);
+#endif
 #endif
   if (active && !muted) {
     sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
