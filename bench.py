@@ -120,6 +120,7 @@ def parse():
     ap.add_argument("--traffic", choices=["live", "profile", "off"], default="live",
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs of the same workload (N=1 only), profile = the committed summary")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run rocprofv3 wraps for --traffic live
+    ap.add_argument("--config5-timeout", type=float, default=240.0, help="seconds after which the config-5 leg is given up (the headline line is printed regardless)")
     ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
     ap.add_argument("--config5-shards", choices=["slabs", "index"], default="slabs", help="x-sorted slabs (boundary sets stay small) or index ranges")
     ap.add_argument("--config5-exchange", choices=["export", "full"], default="export",
@@ -458,15 +459,36 @@ def main():
     if args.pmc_child:
         R.close()
         return
+    def emit():
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        if R.rank == 0:
+            print(json.dumps(out), flush=True)
+
     if args.config5 == "on" or (args.config5 == "auto" and R.world > 1):
-        c5 = config5_leg(args, R)
+        # The headline line must not depend on this second leg: if it fails or does not come back (a rank lost, a collective that
+        # never completes), every rank gives up after --config5-timeout, rank 0 prints the line with the failure recorded, and the
+        # processes leave without waiting for each other.
+        import threading
+
+        def give_up(why):
+            if R.rank == 0:
+                out["config5"] = {"error": why}
+            emit()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.config5_timeout, give_up, args=(f"no result within {args.config5_timeout:.0f} s",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            c5 = config5_leg(args, R)
+        except Exception as e:  # noqa: BLE001 - recorded in the line, the other ranks run into their own timeout
+            give_up(f"{type(e).__name__}: {e}")
+        watchdog.cancel()
         if R.rank == 0:
             out["config5"] = c5
     R.close()
-    sys.stdout.flush()
-    os.dup2(json_fd, 1)
-    if R.rank == 0:
-        print(json.dumps(out), flush=True)
+    emit()
 
 
 if __name__ == "__main__":

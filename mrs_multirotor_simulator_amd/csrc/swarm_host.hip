@@ -1662,7 +1662,7 @@ int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
     HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, ncap, s->stream));
   }
   HIPCHK(mrs_collide_export_translate(s->view(), s->cwork, n_max, rank, s->x_map_recv, s->comm_recv, s->stream));
-  mrs_collide_invalidate_gathered(s->cwork);  // the lists are in export form now: the full exchange would start with a search
+  // (the lists are in export form now; collide.hip remembers that, and the full exchange would start with a search of its own)
   s->x_ok = true;
   s->tau  = 0;
   return MRS_OK;
