@@ -318,11 +318,9 @@ def headline_leg(args, R):
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         moved = BYTES_MOVED_PER_UAV_STEP[key] * n / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None)
-        if args.traffic == "live" and world == 1:
-            traffic, traffic_src = live_traffic(args)
-            if traffic is None:
-                sys.stderr.write(f"bench.py: live PMC traffic unavailable ({traffic_src}); using the committed profile\n")
+        traffic, traffic_src = args.live_traffic  # measured by main() before this process touched the GPU (None, why) otherwise
+        if args.traffic == "live" and world == 1 and traffic is None:
+            sys.stderr.write(f"bench.py: live PMC traffic unavailable ({traffic_src}); using the committed profile\n")
         if traffic is None and args.traffic != "off":
             traffic, traffic_src = pmc_traffic(args, n)
         # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
@@ -452,6 +450,12 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # roofline.traffic: the two rocprofv3 --pmc child runs come FIRST, while this process has not initialised the GPU (children of a
+    # process that holds the device are not started), and not at all when this run is itself being profiled
+    args.live_traffic = (None, "not requested")
+    if args.traffic == "live" and args.gpus == 1 and not args.pmc_child:
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+        args.live_traffic = (None, "this run is itself under a profiler") if profiled else live_traffic(args)
     R = Ranks()
     if R.world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {R.world} rank(s)")

@@ -5,7 +5,7 @@ set -u
 OUT=${PROFILE_OUT:-gpurun_out/profile_round}
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="${BENCH_ARGS:---steps 300 --warmup 50 --no-cpu-baseline}"
+ARGS="${BENCH_ARGS:---steps 300 --warmup 50 --no-cpu-baseline} --traffic profile"  # (no profiler inside a profiled run)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py $ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d" " -f1)
