@@ -329,7 +329,9 @@ def headline_leg(args, R):
         kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
         if 86 * npad * 8 < 2 ** 32:
             fast1 = args.substeps == 1 and args.arith == "fast"
-            kernel_name += "_buf" + ("_w3" if (fast1 and npad // 64 > 2048) else "_nt" if (fast1 and npad // 64 <= (1900 if args.workload == "actuator" else 900)) else "")
+            hbm_stream = fast1 and npad * BYTES_MOVED_PER_UAV_STEP[key] >= 1.4e9  # far beyond the Infinity Cache: two-wave non-temporal kernel
+            kernel_name += "_buf" + ("_nt" if (hbm_stream or (fast1 and npad // 64 <= (1900 if args.workload == "actuator" else 900)))
+                                     else "_w3" if (fast1 and npad // 64 > 2048) else "")
         kernel_name += "_" + args.arith
         # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1

@@ -41,10 +41,11 @@ def _gpu_sample(g, pick):
 
 
 @pytest.mark.parametrize("workload,n,steps", [("actuator", 100_000, 120), ("position", 100_000, 120), ("actuator", 1_000_000, 40),
-                                              ("position", 50_000, 120)])
+                                              ("position", 50_000, 120), ("actuator", 4_000_000, 24), ("position", 2_000_000, 24)])
 def test_bench_launch_against_oracle(mrs, oracle, workload, n, steps):
     """100 k actuator: *_model_step_buf_nt_fast x 2 streams; 100 k position: mrs_uav_step_buf_fast x 2 streams; 1 M actuator:
-    *_model_step_buf_w3_fast x 2 streams; 50 k position: mrs_uav_step_buf_nt_fast on one stream (< 1024 blocks)."""
+    *_model_step_buf_w3_fast x 2 streams; 50 k position: mrs_uav_step_buf_nt_fast on one stream (< 1024 blocks); 4 M actuator and
+    2 M position (>= 1.4 GB moved per step, the HBM-streaming sizes of profiles/): the non-temporal two-wave kernels again."""
     M = mrs
     rng = np.random.default_rng(11)
     st, cmd = _bench_inputs(n, workload, seed=3)
