@@ -10,8 +10,8 @@ sub-record: BASELINE configs[4], 1 000 000 UAVs with mutual collisions sharded o
 Rank 0 prints ONE JSON line.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, repeated until 50 ms
-have been measured.  `ms_per_step` / `value` = the median region's DEVICE time (hipEvent pair on the swarm's stream around the region's
-launches, MAX over ranks): one region of the driver's K = 20 lasts 0.2 ms, a fifth of it host start-up and synchronize latency, which
+have been measured.  `ms_per_step` / `value` = the median region's DEVICE time (hipEvents on the swarm's streams: before the first
+launch, after the last launch of each stream; MAX over ranks): one region of the driver's K = 20 lasts 0.2 ms, a fifth of it host start-up and synchronize latency, which
 is not throughput.  The wall-clock figure of the same regions is in the line too (`wall_ms_per_step`, `value_wall_clock`).
 """
 import argparse
@@ -364,8 +364,9 @@ def headline_leg(args, R):
                          else "whole tick: " + kernel_name + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
                          "concurrent_launches_per_step": launches_per_step,
-                         "method": "one hipEvent pair around each timed region on the swarm's stream (the second stream is joined before the closing "
-                                   "event): elapsed / steps, inter-launch gaps included, median over the regions; with two concurrent half-swarm launches "
+                         "method": "hipEvents around each timed region: one before the first launch, one per stream after its last launch (the later "
+                                   "of the two ends the region; joining the streams afterwards is bookkeeping): elapsed / steps, inter-launch gaps "
+                                   "included, median over the regions; with two concurrent half-swarm launches "
                                    "per step `achieved` is the bytes of both over that time.  `achieved` prices the ALGORITHMIC bytes (SURVEY 8d); "
                                    "`moved_GBps` the bytes the kernel really moves (elided v_prev / F_ext / init_z columns), and `frac_of_achievable` "
                                    "holds those against the 6.3 TB/s a read+write stream reaches.  In the `infinity-cache-resident` regime the state "

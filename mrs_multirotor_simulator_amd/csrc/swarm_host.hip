@@ -278,6 +278,11 @@ struct mrs_swarm {
   // independent, so the drain of one launch overlaps the ramp of the other (tools/two_streams.py: +11 % at 100 k, +19 % at 200 k)
   hipStream_t stream2 = nullptr;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t  ev_end2 = nullptr;   // profiling: end of the second stream's part of a split run (recorded before the join)
+  bool        prof_split = false;  // the end events of the running profile region have been recorded by the split run itself
+  // every C-ABI call bumps op_seq (MRS_LOCK); mrs_swarm_synchronize notes the value it leaves behind: a run of steps that is the very
+  // next call finds both streams idle and starts its second stream without the fork event
+  uint64_t    op_seq = 0, quiet_seq = ~0ull;
   bool        split_steps = true;  // tuning: MRS_SPLIT_STREAMS=0
   // native multi-GPU collision exchange (mrs_swarm_comm_init): RCCL all-gather issued on `stream`
   void*      rccl_comm = nullptr;
@@ -384,9 +389,12 @@ static void track_mode(mrs_swarm* s, int first, int count, int mode) {
   }
 }
 
-#define MRS_LOCK(s)                                           \
-  std::unique_lock<std::recursive_mutex> _lk;                 \
-  if (s) _lk = std::unique_lock<std::recursive_mutex>(const_cast<mrs_swarm*>(s)->mtx)
+#define MRS_LOCK(s)                                                                      \
+  std::unique_lock<std::recursive_mutex> _lk;                                            \
+  if (s) {                                                                               \
+    _lk = std::unique_lock<std::recursive_mutex>(const_cast<mrs_swarm*>(s)->mtx);        \
+    const_cast<mrs_swarm*>(s)->op_seq++;                                                 \
+  }
 
 static int settle(mrs_swarm* s);
 // entry of every call that reads or writes swarm state: collision ticks still pending on the device side are evaluated first
@@ -686,6 +694,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   }
   HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreate(&s->ev_end2));
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
@@ -731,6 +740,7 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->x_map_recv) (void)hipFree(s->x_map_recv);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->ev_end2) (void)hipEventDestroy(s->ev_end2);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -765,6 +775,7 @@ int mrs_swarm_synchronize(mrs_swarm_t* s) {
   int rc = settle(s);  // ticks queued as no-ops behind a stale-list tick are replayed, the last collision tick is evaluated
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(s->stream));
+  s->quiet_seq = s->op_seq;  // (the second stream was joined into this one by whoever used it)
   return MRS_OK;
 }
 
@@ -1003,6 +1014,7 @@ static int join_streams(mrs_swarm* s) {
 static int begin_profile(mrs_swarm* s) {
   s->ev_used          = 0;
   s->region_launches  = 0;
+  s->prof_split       = false;
   if (s->profiling == 1) {
     while (s->ev.size() < 2) {
       hipEvent_t e;
@@ -1020,10 +1032,18 @@ static int finish_profile(mrs_swarm* s) {
     if (rc) return rc;
   }
   if (s->profiling == 1) {
-    HIPCHK(hipEventRecord(s->ev[1], s->stream));
+    // a split run has recorded its own end events, one per stream, before joining the streams: the region ends when the later of
+    // the two halves has finished its last step (the join is stream bookkeeping, not part of the steps)
+    if (!s->prof_split) HIPCHK(hipEventRecord(s->ev[1], s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    if (s->prof_split) {
+      float ms2 = 0;
+      HIPCHK(hipEventElapsedTime(&ms2, s->ev[0], s->ev_end2));
+      if (ms2 > ms) ms = ms2;
+      s->prof_split = false;
+    }
     s->last_launches = s->region_launches;
     s->last_ms       = s->region_launches ? (double)ms / s->region_launches : 0.0;
     return MRS_OK;
@@ -1231,17 +1251,23 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   int rc = upload_types(s, dt);
   if (rc) return rc;
   if ((rc = begin_profile(s))) return rc;
+  bool enqueued = false;  // something of this call is already on the stream
   if (s->collide_since_step && substeps_per_launch == 1) {  // the first step of the run may carry a collision tick
     if ((rc = step_one(s, dt))) return rc;
     n_steps--;
+    enqueued = true;
   }
   if (n_steps > 0) {
+    enqueued = enqueued || !s->log.empty() || s->pend.on || s->f_lazy.on;  // (what settle is about to issue)
     if ((rc = settle(s))) return rc;
     s->p_valid = false;
     // enough launches to overlap, enough blocks for two useful halves, and no per-launch events to keep in order
     static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
     const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
-    if (split && (rc = fork_streams(s))) return rc;
+    // (the call right before this one was mrs_swarm_synchronize and nothing has been enqueued since — not even by the lines above:
+    //  both streams are idle (upload_types synchronises when it copies), the second one needs no event to wait for)
+    const bool quiet = s->quiet_seq + 1 == s->op_seq && !enqueued;
+    if (split && !quiet && (rc = fork_streams(s))) return rc;
     int left = n_steps;
     while (left > 0 && rc == MRS_OK) {
       const int sub = left < substeps_per_launch ? left : substeps_per_launch;
@@ -1249,6 +1275,8 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
       left -= sub;
     }
     if (split) {  // also on a failed launch: nothing else may touch the state before the second stream has been joined
+      if (rc == MRS_OK && s->profiling == 1 && hipEventRecord(s->ev[1], s->stream) == hipSuccess && hipEventRecord(s->ev_end2, s->stream2) == hipSuccess)
+        s->prof_split = true;
       const int rcj = join_streams(s);
       if (rc == MRS_OK) rc = rcj;
     }
