@@ -886,6 +886,40 @@ def test_two_stream_step_runs_equal_single_stream_ones(M, oracle, fast, monkeypa
         assert np.array_equal(results[0][k], results[1][k]), k
 
 
+def test_step_runs_right_after_a_synchronize_skip_the_fork_event_with_identical_results(M, oracle):
+    """A split run that is the first call after mrs_swarm_synchronize starts its second stream without a fork event (both streams are
+    idle); any other call in between brings the event back.  Same results either way, and the profile region (start event, one end
+    event per stream) reports a plausible time."""
+    rng = np.random.default_rng(98)
+    n = 70_001
+    st = random_state(rng, n, 4, tilted=True)
+    goals = np.concatenate([st["x"] + rng.uniform(-3, 3, (n, 3)), rng.uniform(-3, 3, (n, 1))], axis=1)
+    results = []
+    for quiet in (False, True):
+        g = M.Swarm(n, arith=M.ARITH_FAST)
+        g.construct(0, n, M.model_params("x500", ground_enabled=True, ground_z=0.0), st["x"], np.zeros(n))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        g.set_input(0, n, oracle.POSITION_CMD, goals)
+        g.set_profiling(1)
+        times = []
+        for _ in range(4):
+            g.synchronize()
+            if not quiet:
+                g.has_crashed(0, 1)  # any call between the synchronize and the run: the run forks with an event again
+            g.step_n(DT, 6)
+            times.append(g.last_step_kernel_ms())
+            g.set_input(n - 64, 64, oracle.POSITION_CMD, goals[n - 64:])  # host write right behind a split run (ordered after both streams)
+        g.set_profiling(0)
+        s = g.get_state()
+        s["pid"], s["imu"] = g.get_pid(), g.get_imu()
+        results.append(s)
+        for ms, launches in times:
+            assert launches == 6 and 2e-3 < ms < 1.0, (ms, launches)  # per-step device time of a 70 k cascade step: microseconds, not zero
+        del g
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), k
+
+
 def test_gathered_collisions_reuse_neighbour_lists_over_many_ticks(M, oracle):
     """The multi-GPU collision path on two virtual shards of one GPU, 200 ticks of a moving swarm: per tick every shard steps,
     packs its records into the (NaN-padded) gathered buffer and collides against it.  The shards keep neighbour lists over the
