@@ -11,6 +11,8 @@ for v in "$@"; do
   case $kind in
     skin) hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -DMRS_SKIN=$v -c $CS/collide.hip -o /tmp/collide_$tag.o
           hipcc -shared -fPIC --offload-arch=gfx950 -o variants/libmrs_$tag.so $OBJ/step_kernel_literal.o $OBJ/step_kernel_fast.o /tmp/collide_$tag.o $OBJ/outputs.o $OBJ/swarm_host.o ;;
+    collideflag) hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math $v -c $CS/collide.hip -o /tmp/collide_$tag.o
+          hipcc -shared -fPIC --offload-arch=gfx950 -o variants/libmrs_$tag.so $OBJ/step_kernel_literal.o $OBJ/step_kernel_fast.o /tmp/collide_$tag.o $OBJ/outputs.o $OBJ/swarm_host.o ;;
     stepflag) hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=fast -fno-fast-math $v -c $CS/step_kernel_fast.hip -o /tmp/skf_$tag.o
           hipcc -shared -fPIC --offload-arch=gfx950 -o variants/libmrs_$tag.so $OBJ/step_kernel_literal.o /tmp/skf_$tag.o $OBJ/collide.o $OBJ/outputs.o $OBJ/swarm_host.o ;;
   esac
