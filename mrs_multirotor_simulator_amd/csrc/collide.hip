@@ -464,7 +464,7 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
   uint32_t*   hit_overflow;
 };
 
-// C: uniform sweeps over one window of the work list, U independent entries per lane and iteration so that their loads overlap.
+// C: uniform sweeps over one window of the work list, U entries per lane and iteration (see below for U).
 // A chained bucket is walked inside the list: after a member has been evaluated, the next member of its chain is written back —
 // COMPACTED to the front (slot k < the number of entries read so far, so no unread entry is overwritten) — and the shrunken
 // list is swept again until every chain has ended.  Never more entries than the sweep started with: nothing can overflow, and
@@ -472,7 +472,13 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
 template <bool LISTS>
 __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int lane, const PosRecord* rec, const uint2* next, long long wave_first,
                                              int crash) {
-  constexpr int U = 4;
+  // entries per lane and iteration.  Four looked right while the kernel waited on single round trips; since the record loads travel
+  // with the chain links and the later levels are compacted, ONE is fastest (100 k UAVs: 26.9 us, U = 2: 27.8, 4: 29.0, 6: 31.1; at
+  // 16 m^3 per UAV 63.9 vs 68.0): the work list of a wave is 4-5 entries per lane, and what limits it now is the rate of scattered accesses.
+#ifndef MRS_SWEEP_U
+#define MRS_SWEEP_U 1
+#endif
+  constexpr int U = MRS_SWEEP_U;
   while (wn != 0u) {
     if (lane == 0) *L.next_n = 0;  // entries of the next sweep
     __syncthreads();
