@@ -32,7 +32,9 @@ DT = 0.001
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6300.0  # what a plain read+write stream reaches according to the same guide (measured here: 6.0-6.2 TB/s)
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
+INFINITY_CACHE_GBS = 8600.0  # lower bound the same guide measured for reads served by the Infinity Cache (38 MB table, uniformly random rows)
 STATE_BYTES_PER_UAV = 86 * 8 + 4  # swarm_layout.h: F_COUNT doubles + the flag word
+HBM_STREAMING_UAVS = 4_000_000    # 2.8 GB of state, 1.65 GB moved per step: nothing is read twice out of a cache
 
 # algorithmic bytes per UAV-step: one read + one write of everything the step must touch, FP64
 BYTES_PER_UAV_STEP = {
@@ -48,15 +50,15 @@ BYTES_MOVED_PER_UAV_STEP = {"actuator": (18 + 4 + 4) * 8 + 4 + (18 + 3 + 4) * 8,
 COLLISION_BYTES = {"list_tick_per_uav": 28, "list_tick_per_uav_with_partner": 150, "search_tick_per_uav": 92, "search_tick_per_candidate": 24}
 
 
-def pmc_traffic(args, n):
+def pmc_traffic(args, n, workload=None):
     """HBM-side bytes per launch from a committed rocprofv3 PMC summary of this same command (profiles/), corrected as
     MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950 (confirmed by the calibration rows of that summary for this
     8-B/lane SoA pattern), WRITE_SIZE exact, both x1024.  None when no summary matches the configuration."""
-    stem = {"actuator": "step_kernel", "position": "position_cascade"}.get(args.workload)
+    stem = {"actuator": "step_kernel", "position": "position_cascade", "position+collisions": "collision_tick"}.get(workload or args.workload)
     size = f"{n // 1000}k" if n < 1_000_000 else f"{n // 1_000_000}M"
     if stem is None or args.substeps != 1:
         return None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}_{size}_{args.arith}_summary.json")
         if not os.path.exists(path):
             continue
@@ -66,7 +68,7 @@ def pmc_traffic(args, n):
     return None, None
 
 
-def live_traffic(args):
+def live_traffic(args, uavs=None, workload=None):
     """HBM-side bytes per dispatch of the step kernel, MEASURED in this run: two short child runs of the same workload under
     `rocprofv3 --pmc` — FETCH_SIZE and WRITE_SIZE in separate passes, kernel-trace / stats off, as MI355X_MICROARCH.md prescribes —
     corrected as the guide says (FETCH_SIZE x2 on gfx950, both x1024).  The children are ordinary child processes (`-- python
@@ -79,18 +81,25 @@ def live_traffic(args):
     if exe is None:
         return None, "rocprofv3 not found"
     vals = {}
+    uavs = args.uavs if uavs is None else uavs
+    workload = args.workload if workload is None else workload
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mrs_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--uavs", str(args.uavs), "--workload", args.workload, "--arith", args.arith, "--substeps", str(args.substeps),
+               "--uavs", str(uavs), "--workload", workload, "--arith", args.arith, "--substeps", str(args.substeps),
                "--volume-per-uav", str(args.volume_per_uav), "--steps", "64", "--warmup", "16"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
-            acc = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                   if row["Counter_Name"] == ctr and row["Kernel_Name"].startswith("mrs_uav_")]
+            # (the dominant kernel only: a collision workload also runs search kernels and, on its first ticks, plain step kernels)
+            rows = [row for row in csv.DictReader(open(files[0])) if row["Counter_Name"] == ctr and row["Kernel_Name"].startswith("mrs_uav_")]
+            names = {}
+            for row in rows:
+                names[row["Kernel_Name"]] = names.get(row["Kernel_Name"], 0) + 1
+            top = max(names, key=names.get) if names else None
+            acc = [float(row["Counter_Value"]) for row in rows if row["Kernel_Name"] == top]
             if not acc:
                 return None, f"no step-kernel rows for {ctr}"
             vals[ctr] = sum(acc) / len(acc)
@@ -116,7 +125,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-measure-ms", type=float, default=50.0, help="regions of --steps steps are repeated until this much was timed")
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
-                    help="the 1 000 000-UAV collision leg (BASELINE configs[4]); auto = whenever N > 1")
+                    help="the 1 000 000-UAV collision leg (BASELINE configs[4]); auto = at every N for the default workload (one rank: the same "
+                         "path on a one-rank communicator — the figure the N-rank value is divided by)")
+    ap.add_argument("--sub-records", choices=["auto", "on", "off"], default="auto",
+                    help="hbm_streaming (4 M UAVs) and config4 (100 k UAVs with collisions) sub-records; auto = in the default N=1 run")
     ap.add_argument("--traffic", choices=["live", "profile", "off"], default="live",
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs of the same workload (N=1 only), profile = the committed summary")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run rocprofv3 wraps for --traffic live
@@ -272,16 +284,33 @@ def timed_regions(R, run, sync_local, steps, warmup, min_ms, after_region=None):
     return times, extra
 
 
-def headline_leg(args, R):
+def kernel_name_of(n, workload, arith, substeps):
+    """the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
+    non-temporal accesses for small swarms and for swarms far beyond the Infinity Cache"""
+    key = "actuator" if workload == "actuator" else "position"
+    npad = (n + 63) // 64 * 64
+    if workload.endswith("collisions"):
+        return "mrs_uav_step_coll" + ("_buf" if 86 * npad * 8 < 2 ** 32 else "") + "_" + arith
+    name = ("mrs_uav_model_step" if workload == "actuator" else "mrs_uav_step") + ("_multi" if substeps > 1 else "")
+    if 86 * npad * 8 < 2 ** 32:
+        fast1 = substeps == 1 and arith == "fast"
+        hbm_stream = fast1 and npad * BYTES_MOVED_PER_UAV_STEP[key] >= 1.4e9  # far beyond the Infinity Cache: two-wave non-temporal kernel
+        name += "_buf" + ("_nt" if (hbm_stream or (fast1 and npad // 64 <= (1900 if workload == "actuator" else 900)))
+                          else "_w3" if (fast1 and npad // 64 > 2048) else "")
+    return name + "_" + arith
+
+
+def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"), min_ms=None, seed=3):
+    """One timed workload on this rank's GPU: `n` x500 UAVs, regions of exactly `steps` steps (ticks).  Returns (record, st, cmd);
+    the record is built on rank 0 only."""
     import mrs_multirotor_simulator_amd as M
     torch = R.torch
-    n = args.uavs
-    st, cmd = make_inputs(n, args.workload, seed=3 + R.rank, volume_per_uav=args.volume_per_uav)
+    st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav)
     sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
     sw.construct(0, n, M.model_params("x500", ground_enabled=True))
     sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
-    sw.set_input(0, n, M.ACTUATOR_CMD if args.workload == "actuator" else M.POSITION_CMD, cmd)
-    coll = args.workload.endswith("collisions")
+    sw.set_input(0, n, M.ACTUATOR_CMD if workload == "actuator" else M.POSITION_CMD, cmd)
+    coll = workload.endswith("collisions")
 
     def run(k):
         if coll:
@@ -294,12 +323,12 @@ def headline_leg(args, R):
         torch.cuda.synchronize()
 
     if args.pmc_child:  # under rocprofv3 --pmc: just run the launches
-        run(args.warmup)
-        run(args.steps)
+        run(warmup)
+        run(steps)
         sync_local()
-        return None
+        return None, st, cmd
     sw.set_profiling(1)  # one hipEvent pair around every step_n / tick_n call, on the swarm's stream
-    times, ev = timed_regions(R, run, sync_local, args.steps, args.warmup, args.min_measure_ms, after_region=sw.last_step_kernel_ms)
+    times, ev = timed_regions(R, run, sync_local, steps, warmup, args.min_measure_ms if min_ms is None else min_ms, after_region=sw.last_step_kernel_ms)
     sw.set_profiling(0)
     assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
     kern_ms = float(np.median([e[0] for e in ev]))
@@ -313,55 +342,55 @@ def headline_leg(args, R):
     out = None
     if R.rank == 0:
         world = R.world
-        key = "actuator" if args.workload == "actuator" else "position"
+        key = "actuator" if workload == "actuator" else "position"
         # one launch reads and writes the state once, however many sub-steps it fuses: no roofline credit for fusion
         alg_bytes = BYTES_PER_UAV_STEP[key] * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         moved = BYTES_MOVED_PER_UAV_STEP[key] * n / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = args.live_traffic  # measured by main() before this process touched the GPU (None, why) otherwise
-        if args.traffic == "live" and world == 1 and traffic is None:
-            sys.stderr.write(f"bench.py: live PMC traffic unavailable ({traffic_src}); using the committed profile\n")
-        if traffic is None and args.traffic != "off":
-            traffic, traffic_src = pmc_traffic(args, n)
-        # the launcher's choice (step_device.inc): buffer-addressed columns below 4 GiB of state, three-wave variant beyond 2 waves/SIMD,
-        # non-temporal accesses for model-only steps of small swarms
+        tr, tr_src = traffic  # measured by main() before this process touched the GPU; (None, why) otherwise
+        if tr is None and args.traffic != "off":
+            if args.traffic == "live" and world == 1:
+                sys.stderr.write(f"bench.py: live PMC traffic unavailable for {n} UAVs / {workload} ({tr_src}); using the committed profile\n")
+            tr, tr_src = pmc_traffic(args, n, workload)
         npad = (n + 63) // 64 * 64
-        kernel_name = ("mrs_uav_model_step" if args.workload == "actuator" else "mrs_uav_step") + ("_multi" if args.substeps > 1 else "")
-        if 86 * npad * 8 < 2 ** 32:
-            fast1 = args.substeps == 1 and args.arith == "fast"
-            hbm_stream = fast1 and npad * BYTES_MOVED_PER_UAV_STEP[key] >= 1.4e9  # far beyond the Infinity Cache: two-wave non-temporal kernel
-            kernel_name += "_buf" + ("_nt" if (hbm_stream or (fast1 and npad // 64 <= (1900 if args.workload == "actuator" else 900)))
-                                     else "_w3" if (fast1 and npad // 64 > 2048) else "")
-        kernel_name += "_" + args.arith
+        kernel_name = kernel_name_of(n, workload, args.arith, args.substeps)
         # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1
-        if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-args.steps // args.substeps) >= 4:
+        if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-steps // args.substeps) >= 4:
             launches_per_step = 2
-        if traffic is not None:
-            traffic *= launches_per_step  # the PMC summary is per dispatch; `achieved` and `traffic` are both per step
+        if tr is not None:
+            tr *= launches_per_step  # the PMC figure is per dispatch; `achieved` and `traffic` are both per step
         touched = STATE_BYTES_PER_UAV * n
+        resident = touched < INFINITY_CACHE_BYTES
         out = {
-            "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * args.steps / el, "unit": "UAV-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * steps / el, "unit": "UAV-steps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "regions": len(times), "wall_ms_per_step": wall / args.steps * 1e3, "first_region_wall_ms_per_step": times[0] / args.steps * 1e3,
-            "value_wall_clock": world * n * args.steps / wall,
-            "timing": f"{len(times)} regions of exactly {args.steps} steps, each bracketed by barrier + synchronize; ms_per_step / value = median region's "
+            "regions": len(times), "wall_ms_per_step": wall / steps * 1e3, "first_region_wall_ms_per_step": times[0] / steps * 1e3,
+            "value_wall_clock": world * n * steps / wall,
+            "timing": f"{len(times)} regions of exactly {steps} steps, each bracketed by barrier + synchronize; ms_per_step / value = median region's "
                       "device time (hipEvent pair around the region's launches), MAX over ranks; wall_ms_per_step / value_wall_clock = the same "
                       "regions by time.perf_counter() (host start-up and synchronize latency included)",
-            "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {args.workload} references, dt=1 ms, RK4, ground on"
-                       if args.workload == "actuator" else f"{n} x500 UAVs per GPU, {args.workload}, dt=1 ms",
+            "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {workload} references, dt=1 ms, RK4, ground on"
+                       if workload == "actuator" else
+                       (f"BASELINE configs[3]: {n} x500 UAVs, position references + mutual collisions + ground plane, {args.volume_per_uav:g} m^3 per UAV, dt=1 ms"
+                        if coll else f"{n} x500 UAVs per GPU, {workload}, dt=1 ms"),
                        "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
                        "parallelism": f"{world} independent shard(s), no collective on the data path"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "regime": "infinity-cache-resident" if touched < INFINITY_CACHE_BYTES else "hbm-streaming",
+            # `peak` is the HBM3E spec figure in every regime (comparable across sizes); while the touched state fits the 256 MiB Infinity
+            # Cache the operative limit is that cache, not HBM: `bound` says so, and the guide's measured lower bound for it is given
+            "roofline": {"bound": "infinity-cache" if resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
+                         "regime": "infinity-cache-resident" if resident else "hbm-streaming",
+                         "peak_by_regime": {"hbm-streaming": HBM_PEAK_GBS, "infinity-cache-resident": INFINITY_CACHE_GBS},
+                         "frac_of_regime_peak": achieved / (INFINITY_CACHE_GBS if resident else HBM_PEAK_GBS),
                          "touched_bytes": touched,
                          "bytes_moved_per_uav_step": BYTES_MOVED_PER_UAV_STEP[key], "moved_GBps": moved,
                          "frac_moved_of_peak": moved / HBM_PEAK_GBS,
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": moved / HBM_ACHIEVABLE_GBS,
                          "kernel": kernel_name if not coll
-                         else "whole tick: " + kernel_name + " + collision pass (time per tick, bytes of the step only)", "kernel_avg_ms": kern_ms, "launches": n_launch,
+                         else "whole tick: " + kernel_name + " + neighbour search every ~27 ticks (time per tick, bytes of the step only)",
+                         "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
                          "concurrent_launches_per_step": launches_per_step,
                          "method": "hipEvents around each timed region: one before the first launch, one per stream after its last launch (the later "
@@ -370,8 +399,8 @@ def headline_leg(args, R):
                                    "per step `achieved` is the bytes of both over that time.  `achieved` prices the ALGORITHMIC bytes (SURVEY 8d); "
                                    "`moved_GBps` the bytes the kernel really moves (elided v_prev / F_ext / init_z columns), and `frac_of_achievable` "
                                    "holds those against the 6.3 TB/s a read+write stream reaches.  In the `infinity-cache-resident` regime the state "
-                                   "(touched_bytes) fits the 256 MiB Infinity Cache, so HBM bandwidth is not the operative limit there — "
-                                   "profiles/ holds the hbm-streaming runs (>= 4 M UAVs)"},
+                                   "(touched_bytes) fits the 256 MiB Infinity Cache, so HBM bandwidth is not the operative limit there (`bound`); "
+                                   "the `hbm_streaming` sub-record of this line is the same kernel on 4 M UAVs, where every byte comes from HBM"},
         }
         if coll:
             ticks, searches = sw.collision_stats()
@@ -382,15 +411,22 @@ def headline_leg(args, R):
             p = 0.06  # fraction of UAVs with a listed partner at 64 m^3 per UAV
             cb = COLLISION_BYTES["list_tick_per_uav"] + COLLISION_BYTES["list_tick_per_uav_with_partner"] * p
             out["roofline_collision"] = {
-                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "bound": "infinity-cache" if resident else "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "algorithmic_bytes_per_uav_list_tick": cb, "algorithmic_bytes_per_uav_search_tick": "92 + 24 * candidates",
                 "achieved_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9,
                 "frac_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "whole tick = step + collision pass over (step bytes + list-tick bytes); per-kernel times: profiles/r02_collision_tick_*"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, st, cmd)
+                "note": "whole tick = fused step + collision launch, plus the neighbour search amortised over the ticks between two searches, over "
+                        "(step bytes + list-tick bytes); per-kernel times: profiles/r03_collision_tick_*"}
     del sw
-    return out
+    return out, st, cmd
+
+
+SUB_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "regions", "wall_ms_per_step", "value_wall_clock", "config", "roofline", "roofline_collision")
+
+
+def sub_record(rec):
+    """the fields of a full record that a sub-record of the headline line keeps"""
+    return {k: rec[k] for k in SUB_KEYS if k in rec}
 
 
 def config5_leg(args, R):
@@ -426,7 +462,9 @@ def config5_leg(args, R):
         sw.synchronize()
         torch.cuda.synchronize()
 
-    steps, warmup = args.steps, min(args.warmup, 50)
+    # regions of at least 200 ticks: a search comes every ~28 ticks and a call starts with two ticks in the serial form, so
+    # the driver's K = 20 would time the start-up of a call, not the tick
+    steps, warmup = max(args.steps, 200), min(max(args.warmup, 30), 60)
     times, _ = timed_regions(R, run, sync_local, steps, warmup, args.min_measure_ms)
     el = float(np.median(times))
     info = sw.comm_info()
@@ -453,36 +491,61 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    # roofline.traffic: the two rocprofv3 --pmc child runs come FIRST, while this process has not initialised the GPU (children of a
+    subs = args.sub_records == "on" or (args.sub_records == "auto" and args.gpus == 1 and args.workload == "actuator"
+                                        and args.uavs == 100_000 and args.substeps == 1 and not args.pmc_child)
+    # roofline.traffic: the rocprofv3 --pmc child runs come FIRST, while this process has not initialised the GPU (children of a
     # process that holds the device are not started), and not at all when this run is itself being profiled
-    args.live_traffic = (None, "not requested")
+    live = {}
     if args.traffic == "live" and args.gpus == 1 and not args.pmc_child:
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
-        args.live_traffic = (None, "this run is itself under a profiler") if profiled else live_traffic(args)
+        jobs = [(args.uavs, args.workload)] + ([(HBM_STREAMING_UAVS, "actuator"), (100_000, "position+collisions")] if subs else [])
+        for job in jobs:
+            live[job] = (None, "this run is itself under a profiler") if profiled else live_traffic(args, *job)
+    no_traffic = (None, "not requested")
     R = Ranks()
     if R.world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {R.world} rank(s)")
-    out = headline_leg(args, R)
+    out, st, cmd = step_leg(args, R, args.uavs, args.workload, args.steps, args.warmup, traffic=live.get((args.uavs, args.workload), no_traffic))
     if args.pmc_child:
         R.close()
         return
-    def emit():
-        sys.stdout.flush()
-        os.dup2(json_fd, 1)
-        if R.rank == 0:
-            print(json.dumps(out), flush=True)
+    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, st, cmd)
+    del st, cmd
+    if subs:
+        # the numbers the headline size cannot show (each a few seconds): the same kernel where every byte comes from HBM, and BASELINE
+        # config 4 (collisions + ground) in the form tick_n runs it — fused step + collision launches, searches queued ahead
+        rec, _, _ = step_leg(args, R, HBM_STREAMING_UAVS, "actuator", 200, 50, traffic=live.get((HBM_STREAMING_UAVS, "actuator"), no_traffic), min_ms=150.0)
+        out["hbm_streaming"] = sub_record(rec)
+        rec, _, _ = step_leg(args, R, 100_000, "position+collisions", 300, 100, traffic=live.get((100_000, "position+collisions"), no_traffic), min_ms=30.0)
+        out["config4"] = sub_record(rec)
 
-    if args.config5 == "on" or (args.config5 == "auto" and R.world > 1):
+    import threading
+    emit_lock, emitted = threading.Lock(), []
+
+    def emit(extra=None):
+        """prints the ONE JSON line exactly once, whichever thread gets here first (main thread or the config-5 watchdog)"""
+        with emit_lock:
+            if emitted:
+                return False
+            emitted.append(True)
+            if R.rank == 0 and extra:
+                out.update(extra)
+            sys.stdout.flush()
+            os.dup2(json_fd, 1)
+            if R.rank == 0:
+                print(json.dumps(out), flush=True)
+            return True
+
+    if args.config5 == "on" or (args.config5 == "auto" and not args.pmc_child and args.workload == "actuator"):
         # The headline line must not depend on this second leg: if it fails or does not come back (a rank lost, a collective that
         # never completes), every rank gives up after --config5-timeout, rank 0 prints the line with the failure recorded, and the
         # processes leave without waiting for each other.
-        import threading
-
+        # A failed leg still prints the headline line (with config5.error) but the process then leaves with a NON-ZERO status, without
+        # waiting for the other ranks and without re-executing anything: the launcher and the driver can tell it from success.
         def give_up(why):
-            if R.rank == 0:
-                out["config5"] = {"error": why}
-            emit()
-            os._exit(0)
+            emit({"config5": {"error": why}})
+            os._exit(3)
 
         watchdog = threading.Timer(args.config5_timeout, give_up, args=(f"no result within {args.config5_timeout:.0f} s",))
         watchdog.daemon = True
@@ -492,8 +555,11 @@ def main():
         except Exception as e:  # noqa: BLE001 - recorded in the line, the other ranks run into their own timeout
             give_up(f"{type(e).__name__}: {e}")
         watchdog.cancel()
-        if R.rank == 0:
-            out["config5"] = c5
+        if not emit({"config5": c5}):  # the watchdog fired between the leg's return and cancel(): its line (and exit status) stand
+            time.sleep(60)
+            os._exit(3)
+        R.close()
+        return
     R.close()
     emit()
 

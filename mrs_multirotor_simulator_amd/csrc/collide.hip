@@ -784,6 +784,9 @@ extern "C" hipError_t mrs_launch_pack_positions(SwarmDev sw, PosRecord* out, hip
   return hipGetLastError();
 }
 
+// the mode word the collision code passes around as `crash` (collide_device.inc): the flavour of the force expression follows the swarm
+static inline int mode_word(const SwarmDev& sw, int crash) { return (crash ? MRS_MODE_CRASH : 0) | (sw.fast ? MRS_MODE_FAST : 0); }
+
 #define CK(e)                        \
   do {                               \
     hipError_t _e = (e);             \
@@ -841,6 +844,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
                                       int crash, double rebounce, int rec_is_local_scratch, hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
+  crash = mode_word(sw, crash);
   CK(ensure_tables(w, n_total, st));
   w->lists_live = false;  // the step kernel stops testing; a later list tick starts with a rebuild
   w->g_lists_live = false;
@@ -883,6 +887,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   if (!*work) *work = new CollideWork();
   CollideWork*    w = *work;
   const long long n = sw.n;
+  crash = mode_word(sw, crash);
   CK(ensure_tables(w, n, st));
   if (!w->rec_build) CK(hipMalloc(&w->rec_build, sizeof(PosRecord) * (size_t)w->cap_n));
   if (!w->nbr) {
@@ -922,6 +927,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
                                                      int crash, double rebounce, int force_rebuild, hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
+  crash = mode_word(sw, crash);
   CK(ensure_tables(w, n_total, st));
   if (!w->nbr) {
     CK(hipMalloc(&w->nbr, sizeof(uint32_t) * (size_t)LIST_CAP * (size_t)w->cap_n));
@@ -1011,7 +1017,8 @@ extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w)
 // forget a stall (the host has synchronised the stream and is about to repeat the search)
 extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st) {
   if (!w || !w->fctl) return hipSuccess;
-  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * 2, st));
+  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * 2, st));                                   // stall, progress
+  CK(hipMemsetAsync(w->fctl + CTL_WARN, 0, sizeof(uint32_t), st));  // tau restarts at 1: a stale warning index would swallow the next warning of that index
   w->hostw[CTL_STALL]    = 0u;
   w->hostw[CTL_PROGRESS] = 0u;
   w->hostw[CTL_WARN]     = 0u;
@@ -1229,6 +1236,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
 
 extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st) {
   if (sw.n <= 0) return hipSuccess;
+  cd.crash = mode_word(sw, cd.crash);
   hipLaunchKernelGGL(k_list_eval_cd<false>, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
   return hipGetLastError();
 }
@@ -1239,7 +1247,7 @@ extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int p
   CollDev cd;
   memset(&cd, 0, sizeof cd);
   cd.nbr = w->nbr; cd.nbr_cnt = w->nbr_cnt; cd.rec = w->rec_build; cd.p_in = w->P[pin & 1];
-  cd.rebounce = rebounce; cd.n = sw.n; cd.eval = 1; cd.crash = crash; cd.world = 1;
+  cd.rebounce = rebounce; cd.n = sw.n; cd.eval = 1; cd.crash = mode_word(sw, crash); cd.world = 1;
   hipLaunchKernelGGL(k_list_eval_cd<true>, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
   return hipGetLastError();
 }

@@ -375,7 +375,7 @@ struct mrs_swarm {
   bool      fext_active = false;  // apply_force / collisions were used at least once
 
   SwarmDev view() const {
-    SwarmDev v{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size(), fext_active ? 1u : 0u, nullptr, nullptr, 0.0, 0, 0};
+    SwarmDev v{dS, dF, dT, dDiag, dBT, dMB, n, npad, (int32_t)mixed_blocks.size(), fext_active ? 1u : 0u, nullptr, nullptr, 0.0, 0, arith == MRS_ARITH_FAST ? 1 : 0};
     mrs_collide_step_hook(cwork, &v.vl_rec, &v.vl_flag, &v.vl_lim2);
     return v;
   }
@@ -1087,12 +1087,35 @@ static bool fused_usable(const mrs_swarm* s) {
   return s->use_lists && s->use_fused && s->fk_ok && s->p_valid && !s->nbr_dirty && !s->blocks_dirty && !s->types_dirty && s->cwork != nullptr;
 }
 
+// The host runs at most `lead` launches ahead of its device: it waits (spinning on the pinned progress word, no synchronisation)
+// until launch `index - lead` has started or some launch has reported stale lists.  A device that makes no progress for
+// MRS_PROGRESS_TIMEOUT_S seconds (default 30; a wedged kernel, a collective whose peer is gone) is an error, returned with the words
+// the host last saw — after it the swarm's stream, and for a sharded swarm its communicator, must be considered dead: destroy the
+// swarm from a fresh process (never re-exec a process that has touched the GPU).
+static int wait_for_progress(mrs_swarm* s, const volatile unsigned* hw, unsigned index, int lead) {
+  if (!hw) return MRS_OK;
+  auto behind = [&]() { return (int)(index - hw[CTL_PROGRESS]) > lead && hw[CTL_STALL] == 0u; };
+  if (!behind()) return MRS_OK;
+  static const double limit_s = getenv("MRS_PROGRESS_TIMEOUT_S") ? atof(getenv("MRS_PROGRESS_TIMEOUT_S")) : 30.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long spins = 1; behind(); spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFFul) != 0) continue;
+    const hipError_t q = hipStreamQuery(s->stream);  // a launch that failed asynchronously never writes its words
+    if (q != hipSuccess && q != hipErrorNotReady) return fail(MRS_ERR_HIP, std::string("fused launches: ") + hipGetErrorString(q));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+      return fail(MRS_ERR_HIP, "the device made no progress for " + std::to_string((int)limit_s) + " s: waiting for launch " + std::to_string(index - (unsigned)lead) +
+                                   ", progress word " + std::to_string(hw[CTL_PROGRESS]) + ", stall word " + std::to_string(hw[CTL_STALL]) + ", warning word " +
+                                   std::to_string(hw[CTL_WARN]) + " (the stream" + (s->comm_world > 1 ? " and the communicator are" : " is") + " dead: use a fresh process)");
+  }
+  return MRS_OK;
+}
+
 // one fused launch: evaluate collision tick `e.eval` (if any) from the lists, then makeStep(e.dt)
 static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
   const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
   // do not run further ahead of the device than a few launches: when the lists go stale at tick T everything queued behind T is wasted
-  for (long spins = 0; hw && (int)(s->tau - hw[CTL_PROGRESS]) > s->fused_lead && hw[CTL_STALL] == 0u && spins < 200000000L; spins++)
-    __builtin_ia32_pause();
+  if (int rcw = wait_for_progress(s, hw, s->tau, s->fused_lead)) return rcw;
   if (e.dt != s->table_dt) {  // (a replayed tick of another dt: the motor-filter constants of the type table follow)
     int rc = upload_types(s, e.dt);
     if (rc) return rc;
@@ -1265,8 +1288,9 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
     static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
     const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
     // (the call right before this one was mrs_swarm_synchronize and nothing has been enqueued since — not even by the lines above:
-    //  both streams are idle (upload_types synchronises when it copies), the second one needs no event to wait for)
-    const bool quiet = s->quiet_seq + 1 == s->op_seq && !enqueued;
+    //  both streams are idle (upload_types synchronises when it copies), the second one needs no event to wait for;
+    //  a caller holding the handle of mrs_swarm_stream() may have enqueued work of its own without an ABI call: the query sees that)
+    const bool quiet = s->quiet_seq + 1 == s->op_seq && !enqueued && hipStreamQuery(s->stream) == hipSuccess;
     if (split && !quiet && (rc = fork_streams(s))) return rc;
     int left = n_steps;
     while (left > 0 && rc == MRS_OK) {
@@ -1752,12 +1776,15 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     }
     // ---- a segment of fused ticks ----
     const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+    if (!hw) return fail(MRS_ERR_HIP, "export-set exchange: the control words of the fused launches do not exist");
     const unsigned first = s->tau + 1;                                 // launch indices run on from the last search
     unsigned       last  = s->tau + (unsigned)(n_ticks - done);       // ... to the end of the call, unless a word says otherwise
     mrs_swarm::Collide off;
     while (s->tau < last) {
       const unsigned next = s->tau + 1;
-      for (long spins = 0; (int)(next - hw[CTL_PROGRESS]) > (int)lead && hw[CTL_STALL] == 0u && spins < 2000000000L; spins++) __builtin_ia32_pause();
+      // (a device that makes no progress is an ERROR here, never a reason to launch anyway: lock-step of the ranks rests on every host
+      //  having seen the words of launch next - lead - 1 before it issues launch `next`)
+      if ((rc = wait_for_progress(s, hw, next, (int)lead))) return rc;
       const unsigned T = hw[CTL_STALL], W = hw[CTL_WARN];
       if (T != 0u && T + lead + 1 < last) last = T + lead + 1;
       if (W != 0u && W + search_ahead - 1 < last) last = W + search_ahead - 1;

@@ -80,7 +80,7 @@ struct SwarmDev {
   uint32_t*           vl_flag;  // set to 1 when some UAV is farther than sqrt(vl_lim2) from that position
   double              vl_lim2;
   int32_t             blk0;     // step kernels: first 64-UAV block of this launch (a step may be split over two streams)
-  int32_t             _pad2;
+  int32_t             fast;     // MRS_ARITH_FAST swarm: the stand-alone collision passes use the FAST force expression too (collide_device.inc)
 };
 
 // 48-byte record exchanged for the collision pass (single- and multi-GPU): everything
