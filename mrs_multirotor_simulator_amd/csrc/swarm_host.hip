@@ -220,6 +220,19 @@ static void derive_type(const TypeKey& k, double dt, TypeParams& t) {
   t.vel_kp = k.vel.kp; t.vel_kd = k.vel.kd; t.vel_ki = k.vel.ki; t.vel_sat = k.vel.max_acceleration;
   t.att_kp = k.att.kp; t.att_kd = k.att.kd; t.att_ki = k.att.ki;
   t.att_sat_rp = k.att.max_rate_roll_pitch; t.att_sat_yaw = k.att.max_rate_yaw;
+  {  // displacement bound (swarm_layout.h): thrust <= sum_m |alloc[3][m]| max(rpm_m, max_rpm)^2 <= |thrust now| + cap, times 1.5 for the
+     // re-orthonormalised body z of a not quite orthonormal R
+    double cap = 0.0;
+    bool   ok  = p.mass > 0 && p.max_rpm >= 0;
+    for (int m = 0; m < p.n_motors; m++) {
+      const double a = p.allocation_matrix[3 * MRS_MAX_MOTORS + m];
+      if (!(a >= 0)) ok = false;
+      cap += fabs(a) * p.max_rpm * p.max_rpm;
+    }
+    t.pred_a0   = ok ? fabs(p.g) + 1.5 * cap / p.mass : INFINITY;
+    t.pred_thr  = ok ? 1.5 / p.mass : INFINITY;
+    t.pred_drag = ok ? fabs(t.resist_k) / p.mass : INFINITY;
+  }
   for (int i = 0; i < 3; i++) {
     t.rate_kp[i] = k.rate.kp * p.J[i * 3 + i];
     t.rate_kd[i] = k.rate.kd * p.J[i * 3 + i];

@@ -62,6 +62,11 @@ struct TypeParams {
   double  vel_kp, vel_kd, vel_ki, vel_sat;                 // velocity_controller.hpp:108-119
   double  att_kp, att_kd, att_ki, att_sat_rp, att_sat_yaw; // attitude_controller.hpp:160-171
   double  rate_kp[3], rate_kd[3], rate_ki[3];              // gains * J(i,i), rate_controller.hpp:56-65
+  // displacement bound of the sharded collision tick ("prediction"): |acceleration| over the coming steps is at most
+  //   pred_a0 + pred_thr * |allocation*rpm^2 thrust of this step| + (listed partners) * |rebounce| + pred_drag * speed^2
+  double  pred_a0;    // g + 1.5 * (sum_m |alloc[3][m]|) * max_rpm^2 / mass; +inf when the bound cannot be given (a negative thrust column)
+  double  pred_thr;   // 1.5 / mass
+  double  pred_drag;  // |resist_k| / mass
 };
 
 // ---- device view of a swarm ----
@@ -113,8 +118,21 @@ enum {
   CTL_EXPORTS = 4,   // export-set search: number of own UAVs that some other rank lists
   CTL_WARN = 5,      // tick index of the last launch in which some UAV was beyond the WARNING part of its skin: the host schedules the
                      // next search ahead of time, in stream order, instead of waiting for the stall (host mirror only)
-  CTL_WORDS = 8
+  // split sharded ticks (interior / boundary launches on two streams): the boundary chain mirrors what it knows into host
+  // words of its own — one writer per word at any time; the host takes the smaller non-zero of a pair
+  CTL_STALL2 = 6,
+  CTL_WARN2 = 7,
+  CTL_ERROR = 8,     // bit 0: a bounded in-kernel wait ran out; bit 1: a UAV left its skin without the displacement bound announcing it
+  CTL_DONE_B = 9,    // tick index of the last boundary launch all of whose blocks have finished
+  CTL_TICKET_B = 10, // arrivals of boundary-launch blocks (cumulative since the hand-off words were last reset)
+  CTL_NBND = 11,     // 64-UAV blocks of this rank that hold a boundary UAV (set by the search)
+  CTL_WORDS = 16
 };
+// class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)
+#define MRS_BLK_BOUNDARY 1u  // some UAV of the block lists a foreign UAV: the block is stepped by the boundary launch
+#define MRS_BLK_LAYER1   2u  // interior block, some UAV of it lists a UAV of a boundary block: waits for that block's epoch word
+#define MRS_PRED_HORIZON 4u  // steps by which "may leave its skin" is announced ahead (why 4: DESIGN §5)
+enum { MRS_PART_FULL = 0, MRS_PART_INTERIOR = 1, MRS_PART_BOUNDARY = 2 };
 
 struct CollDev {
   const uint32_t*     nbr;      // [LIST_CAP][n]: row k, UAV i at nbr[k * n + i]; ascending partner order
@@ -132,5 +150,12 @@ struct CollDev {
   double              rebounce, lim2, lim2_warn;
   uint32_t            tau;      // tick index of this launch (1, 2, ... since the host last drained the stream)
   int32_t             n, eval, crash, world, block;  // block = 1 + cap
-  int32_t             write_force, _pad;             // latch the evaluated force in the F_ext columns as well
+  int32_t             write_force, part;             // latch the evaluated force in the F_ext columns as well; MRS_PART_*
+  // split sharded ticks: block classes, the boundary launch's block list, per-block epoch words (tick index of the last launch that
+  // finished the block), and the displacement bound's step-dependent factors
+  const uint32_t*     blk_class;  // [blocks]
+  const uint32_t*     blk_list;   // [n_bnd]
+  uint32_t*           epoch;      // [blocks]
+  uint32_t            ticket_target, n_bnd;
+  double              pred_hdt;   // horizon * dt
 };

@@ -97,11 +97,12 @@ def test_config4_bench_form_against_oracle(mrs, oracle, volume):
     """100 000 x500 UAVs, FAST, mrs_swarm_tick_n over 300 ticks: `mrs_uav_step_coll_buf_fast` launches, neighbour searches queued
     ahead of time and — thanks to a few fast UAVs — at least one stall with replayed launches.  Checked against
       (1) the oracle on the UAVs of a sub-box, of which only those are compared that provably never felt a UAV outside the sample:
-          the run is cut into chunks of 25 ticks; at every cut the positions of ALL UAVs are read back and a sample UAV closer than
+          the run is cut into chunks of 25 (10) ticks; at every cut the positions of ALL UAVs are read back and a sample UAV closer than
           contact range + 2 x (largest displacement of a chunk) to an outside UAV, or to a tainted sample UAV, is tainted from then on;
       (2) the same 300 ticks in ONE tick_n call on a second swarm (the form the bench times; the chunked run settles at every cut)."""
     M = mrs
-    n, ticks, chunk, vcap = 100_000, 300, 25, 12.0
+    n, ticks, vcap = 100_000, 300, 14.0
+    chunk = 25 if volume == 64.0 else 10  # the denser swarm needs the shorter reach (contact range + 2 * vcap * chunk * dt) to keep taint local
     import bench
     st, cmd = bench.make_inputs(n, "position+collisions", seed=3, volume_per_uav=volume)
     rng = np.random.default_rng(44)
