@@ -247,6 +247,19 @@ int mrs_swarm_comm_init_custom(mrs_swarm_t* s, int32_t world, int32_t rank, int6
 int mrs_loopback_group_create(int32_t world, mrs_loopback_group_t** out);
 int mrs_loopback_group_destroy(mrs_loopback_group_t* g);
 int mrs_swarm_comm_init_loopback(mrs_swarm_t* s, mrs_loopback_group_t* g, int32_t rank, int64_t n_total);
+/* test hooks of the sharded tick (tests/test_sharded_chaos_gpu.py):
+ *   mrs_loopback_group_set_rendezvous : the group's all-gather without its two host barriers — a rank waits only until every peer
+ *       has ARRIVED at the same collective (before the group's first collective);
+ *   mrs_swarm_debug_chaos : this rank's host sleeps a random 0..max_sleep_us before every launch and, at random, decides on the
+ *       stall / warning words as it read them one launch earlier — host skew the protocol must tolerate (0 switches it off);
+ *   mrs_swarm_get_split_stats : ticks this rank ran in the split form (interior and boundary launches on two streams) and the
+ *       64-UAV blocks its boundary launch covers since the last search */
+int mrs_loopback_group_set_rendezvous(mrs_loopback_group_t* g, int32_t on);
+int mrs_swarm_debug_chaos(mrs_swarm_t* s, int32_t max_sleep_us, uint64_t seed);
+int mrs_swarm_get_split_stats(mrs_swarm_t* s, int64_t* split_ticks, int64_t* boundary_blocks);
+/* test / measurement hook: a kernel that keeps `stream` (a hipStream_t of this process) busy for `microseconds` — stands in for the
+ * latency of a collective in tools/sharded_rank_cost.py */
+int mrs_debug_stream_delay(void* stream, double microseconds);
 int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange);
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
 int mrs_swarm_comm_destroy(mrs_swarm_t* s);

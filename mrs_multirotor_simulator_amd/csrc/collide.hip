@@ -730,7 +730,9 @@ struct CollideWork {
   bool       g_export_form = false;  // the last gathered search was one of the export-set exchange: lists end up in slot form, and of
                                      // the record copy only this rank's own range (the skin references) is kept
   // fused step + collision evaluation (step_device.inc *_coll): double-buffered positions, control words, pinned host mirror
-  Pos4*     P[2]  = {nullptr, nullptr};
+  // (three buffers: in a split sharded tick the interior launch of tick t+1 writes its output while the boundary launch of tick t
+  //  still reads its input — with two buffers those would be the same array)
+  Pos4*     P[3]  = {nullptr, nullptr, nullptr};
   int       pcur  = 0;        // P[pcur] holds the positions after the most recent step (when the host says they are valid)
   long long p_cap = 0;
   uint32_t* fctl  = nullptr;  // CTL_WORDS device words
@@ -738,6 +740,9 @@ struct CollideWork {
   // export-set exchange (multi-GPU ticks between searches): own UAVs listed by another rank, their slots in the padded collective
   uint32_t*     exp_slot = nullptr;   // [n_local]
   long long     exp_slot_cap = 0;
+  // split sharded ticks: class of every 64-UAV block, list of the boundary blocks, epoch word per block (swarm_layout.h)
+  uint32_t *    blk_class = nullptr, *blk_list = nullptr, *epoch = nullptr;
+  long long     blk_cap = 0;
   Pos4*         x_send = nullptr;     // [1 + x_cap]: header + exported positions of this rank
   Pos4*         x_recv = nullptr;     // [world][1 + x_cap]
   PartnerConst* x_const = nullptr;    // [world][1 + x_cap]
@@ -753,9 +758,12 @@ static void free_work(CollideWork* w) {
   (void)hipFree(w->exp_slot); (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
   w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
   w->exp_slot_cap = w->x_cap = 0;
-  (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->fctl);
+  (void)hipFree(w->blk_class); (void)hipFree(w->blk_list); (void)hipFree(w->epoch);
+  w->blk_class = w->blk_list = w->epoch = nullptr;
+  w->blk_cap = 0;
+  (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->P[2]); (void)hipFree(w->fctl);
   if (w->hostw) (void)hipHostFree(w->hostw);
-  w->P[0] = w->P[1] = nullptr;
+  w->P[0] = w->P[1] = w->P[2] = nullptr;
   w->p_cap = 0;
   w->fctl = w->hostw = nullptr;
   w->g_rec_build = nullptr;
@@ -829,9 +837,10 @@ static hipError_t ensure_fused(CollideWork* w, long long n, hipStream_t st) {
   }
   if (n > w->p_cap) {
     CK(hipStreamSynchronize(st));
-    (void)hipFree(w->P[0]); (void)hipFree(w->P[1]);
+    (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->P[2]);
     CK(hipMalloc(&w->P[0], sizeof(Pos4) * (size_t)n));
     CK(hipMalloc(&w->P[1], sizeof(Pos4) * (size_t)n));
+    CK(hipMalloc(&w->P[2], sizeof(Pos4) * (size_t)n));
     w->p_cap = n;
     w->pcur  = 0;
   }
@@ -994,7 +1003,7 @@ extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, 
   cd->nbr_cnt  = w->nbr_cnt;
   cd->rec      = w->rec_build;
   cd->p_in     = w->P[w->pcur];
-  cd->p_out    = w->P[w->pcur ^ 1];
+  cd->p_out    = w->P[(w->pcur + 1) % 3];
   cd->ctl      = w->fctl;
   cd->hostw    = w->hostw;
   cd->rebounce = rebounce;
@@ -1009,7 +1018,7 @@ extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, 
   cd->write_force = 0;  // the host re-derives the force when it is asked for (mrs_collide_latch_force)
   return hipSuccess;
 }
-extern "C" void mrs_collide_fused_advance(CollideWork* w) { w->pcur ^= 1; }
+extern "C" void mrs_collide_fused_advance(CollideWork* w) { w->pcur = (w->pcur + 1) % 3; }
 
 // pinned host mirror of the stall / progress words (read without synchronising: the kernels store them with system scope)
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w) { return w ? w->hostw : nullptr; }
@@ -1022,6 +1031,7 @@ extern "C" hipError_t mrs_collide_fused_reset(CollideWork* w, hipStream_t st) {
   w->hostw[CTL_STALL]    = 0u;
   w->hostw[CTL_PROGRESS] = 0u;
   w->hostw[CTL_WARN]     = 0u;
+  w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
   return hipSuccess;
 }
 
@@ -1050,7 +1060,7 @@ __global__ void k_fill_positions(SwarmDev sw, Pos4* pos_now) {
 
 // map: [0] export count of this rank, [1] lanes over the list capacity so far, [2 + i] slot of own UAV i
 __global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot, uint32_t* map,
-                              uint32_t* fctl) {
+                              uint32_t* fctl, uint32_t* blk_class) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t cnt = nbr_cnt[i];
@@ -1063,6 +1073,45 @@ __global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* 
   if (exported) e = atomicAdd(&fctl[CTL_EXPORTS], 1u);
   exp_slot[i] = e;
   map[2 + i]  = e;
+  if (exported) atomicOr(&blk_class[i >> 6], MRS_BLK_BOUNDARY);  // the block is stepped by the boundary launch of a split tick
+}
+
+// the boundary blocks in a list (any order), their number in the control word the host reads with the export counts
+__global__ void k_class_list(int n_blocks, const uint32_t* blk_class, uint32_t* blk_list, uint32_t* fctl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  if (blk_class[b] & MRS_BLK_BOUNDARY) blk_list[atomicAdd(&fctl[CTL_NBND], 1u)] = (uint32_t)b;
+}
+
+// interior blocks that list a UAV of a boundary block (translated lists: a local entry is the UAV's index)
+__global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* blk_class) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (blk_class[i >> 6] & MRS_BLK_BOUNDARY)) return;
+  const uint32_t cnt = nbr_cnt[i];
+  bool           l1  = false;
+  for (uint32_t k = 0; k < cnt; k++) {
+    const uint32_t e = nbr[(size_t)k * (size_t)n + (size_t)i];
+    if (!(e & MRS_NBR_FOREIGN) && (blk_class[e >> 6] & MRS_BLK_BOUNDARY)) l1 = true;
+  }
+  if (l1) atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1);
+}
+
+// header of this rank's export block := the smallest stall / warning index the rank knows of (end of a segment of ticks: what its
+// interior launches reported last has not travelled yet)
+__global__ void k_header_refresh(Pos4* send, const uint32_t* fctl) {
+  send[0].w = (double)fctl[CTL_STALL];
+  send[0].z = (double)fctl[CTL_WARN];
+}
+
+// start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet
+__global__ void k_handoff_init(uint32_t* fctl, uint32_t* epoch, int n_blocks, uint32_t tau) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_blocks) epoch[b] = tau;
+  if (b == 0) {
+    fctl[CTL_DONE_B]   = tau;
+    fctl[CTL_DONE_I0]  = tau;
+    fctl[CTL_TICKET_B] = 0u;
+  }
 }
 
 __global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint32_t* ctl) {
@@ -1146,6 +1195,8 @@ __global__ void k_fold_stall(const Pos4* x_recv, int world, int block, uint32_t*
   fctl[CTL_WARN]  = warn;
   __hip_atomic_store(&hostw[CTL_STALL], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&hostw[CTL_WARN], warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&hostw[CTL_STALL2], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (nothing else runs: both chains' mirrors agree)
+  __hip_atomic_store(&hostw[CTL_WARN2], warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (progress_tau != 0u && (stall == 0u || progress_tau <= stall))
     __hip_atomic_store(&hostw[CTL_PROGRESS], progress_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1162,6 +1213,17 @@ extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work
     (void)hipFree(w->exp_slot);
     CK(hipMalloc(&w->exp_slot, sizeof(uint32_t) * (size_t)(sw.n > 0 ? sw.n : 1)));
     w->exp_slot_cap = sw.n;
+  }
+  const long long n_blocks = ((long long)(sw.n > 0 ? sw.n : 1) + 63) / 64;
+  if (n_blocks > w->blk_cap) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->blk_class); (void)hipFree(w->blk_list); (void)hipFree(w->epoch);
+    CK(hipMalloc(&w->blk_class, sizeof(uint32_t) * (size_t)n_blocks));
+    CK(hipMalloc(&w->blk_list, sizeof(uint32_t) * (size_t)n_blocks));
+    CK(hipMalloc(&w->epoch, sizeof(uint32_t) * (size_t)n_blocks));
+    CK(hipMemsetAsync(w->blk_class, 0, sizeof(uint32_t) * (size_t)n_blocks, st));
+    CK(hipMemsetAsync(w->epoch, 0, sizeof(uint32_t) * (size_t)n_blocks, st));
+    w->blk_cap = n_blocks;
   }
   if (cap > w->x_cap || world != w->x_world) {
     CK(hipStreamSynchronize(st));
@@ -1180,17 +1242,36 @@ extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work
   return hipSuccess;
 }
 
+// one wave that watches the 100 MHz wall clock for `microseconds` (mrs_debug_stream_delay: stands in for a collective's latency)
+namespace {
+__global__ void k_stream_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  unsigned        k  = 0;
+  while (wall_clock64() - t0 < ticks && k < 400000000u) k++;
+}
+}  // namespace
+extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microseconds) {
+  hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, st, (long long)(microseconds * 100.0));
+  return hipGetLastError();
+}
+
 extern "C" long long mrs_collide_export_capacity(const CollideWork* w) { return w ? w->x_cap : 0; }
+extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w) { return w ? w->fctl : nullptr; }
 extern "C" void*     mrs_collide_export_send(const CollideWork* w) { return w ? (void*)w->x_send : nullptr; }
 extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? (void*)w->x_recv : nullptr; }
 
 // after a search over gathered records: mark the export set, write this rank's slot map (2 + n_max words) for the all-gather
 extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st) {
-  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_WORDS, st));
+  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_ERROR, st));  // (the error word stays: it is reported at the end of the call)
+  CK(hipMemsetAsync(w->fctl + CTL_ERROR + 1, 0, sizeof(uint32_t) * (CTL_WORDS - CTL_ERROR - 1), st));
   CK(hipMemsetAsync(map_send, 0xFF, sizeof(uint32_t) * (size_t)(n_max + 2), st));  // padding UAVs: no slot
-  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = 0u;
+  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
   if (sw.n > 0) {
-    hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl);
+    const int n_blocks = (sw.n + 63) / 64;
+    CK(hipMemsetAsync(w->blk_class, 0, sizeof(uint32_t) * (size_t)n_blocks, st));
+    hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl,
+                       w->blk_class);
+    hipLaunchKernelGGL(k_class_list, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, w->blk_class, w->blk_list, w->fctl);
     hipLaunchKernelGGL(k_fill_positions, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur]);
   }
   hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, st, map_send, w->fctl, w->ctl ? w->ctl : w->fctl);  // (a rank without UAVs never searched: word 6 of fctl is 0)
@@ -1203,6 +1284,7 @@ extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, 
   if (sw.n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, n_max + 2, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
                      maps, rec_all, w->x_recv, w->x_const, w->fctl);
+  hipLaunchKernelGGL(k_class_layer1, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, w->nbr, w->nbr_cnt, w->blk_class);
   return hipGetLastError();
 }
 
@@ -1215,7 +1297,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->nbr_cnt  = w->nbr_cnt;
   cd->rec      = w->g_rec_build + my_offset;
   cd->p_in     = w->P[w->pcur];
-  cd->p_out    = w->P[w->pcur ^ 1];
+  cd->p_out    = w->P[(w->pcur + 1) % 3];
   cd->ctl      = w->fctl;
   cd->hostw    = w->hostw;
   cd->g_pos    = w->x_recv;
@@ -1231,7 +1313,35 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->crash    = crash;
   cd->world    = w->x_world;
   cd->block    = (int)(w->x_cap + 1);
+  cd->part      = MRS_PART_FULL;
+  cd->blk_class = w->blk_class;
+  cd->blk_list  = w->blk_list;
+  cd->epoch     = w->epoch;
+  cd->pred_lim  = 0.5 * SKIN * (1.0 - 1e-9);
+  cd->pred_hdt  = INFINITY;  // (the caller sets horizon * dt: mrs_collide_export_part)
   return hipSuccess;
+}
+
+// the part of a split tick this launch is (MRS_PART_*), the arrivals that complete a boundary launch, the step of the displacement bound
+extern "C" void mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, unsigned ticket_target, double dt, int bound_ok) {
+  cd->part          = part;
+  cd->n_bnd         = n_bnd;
+  cd->ticket_target = ticket_target;
+  cd->pred_hdt      = bound_ok ? (double)MRS_PRED_HORIZON * dt : INFINITY;
+}
+
+extern "C" hipError_t mrs_collide_export_header_refresh(CollideWork* w, hipStream_t st) {
+  if (!w || !w->x_send || !w->fctl) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_header_refresh, dim3(1), dim3(1), 0, st, w->x_send, w->fctl);
+  return hipGetLastError();
+}
+
+// a run of split ticks starts behind launch `tau` (everything before it has completed in stream order)
+extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st) {
+  if (!w || !w->epoch) return hipErrorInvalidValue;
+  const int n_blocks = (n + 63) / 64;
+  hipLaunchKernelGGL(k_handoff_init, dim3((n_blocks + 255) / 256), dim3(256), 0, st, w->fctl, w->epoch, n_blocks, tau);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st) {
@@ -1246,7 +1356,7 @@ extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int p
   if (sw.n <= 0 || !w || !w->P[0]) return hipSuccess;
   CollDev cd;
   memset(&cd, 0, sizeof cd);
-  cd.nbr = w->nbr; cd.nbr_cnt = w->nbr_cnt; cd.rec = w->rec_build; cd.p_in = w->P[pin & 1];
+  cd.nbr = w->nbr; cd.nbr_cnt = w->nbr_cnt; cd.rec = w->rec_build; cd.p_in = w->P[pin % 3];
   cd.rebounce = rebounce; cd.n = sw.n; cd.eval = 1; cd.crash = mode_word(sw, crash); cd.world = 1;
   hipLaunchKernelGGL(k_list_eval_cd<true>, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, cd);
   return hipGetLastError();

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -13,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <dlfcn.h>
@@ -61,8 +63,12 @@ extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** re
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void mrs_collide_free(CollideWork* w);
-extern "C" hipError_t mrs_launch_step_coll_literal(SwarmDev sw, CollDev cd, double dt, int variant, hipStream_t st);
-extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double dt, int variant, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_coll_literal(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
+extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
+extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, unsigned ticket_target, double dt, int bound_ok);
+extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
+extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
+extern "C" hipError_t mrs_collide_export_header_refresh(CollideWork* w, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
@@ -317,6 +323,19 @@ struct mrs_swarm {
   int64_t   x_export_count = 0;
   std::vector<unsigned> x_last_overflow;
   int64_t   x_searches = 0, x_ticks = 0, x_noop_ticks = 0;
+  // split sharded ticks: between two searches the blocks that hold a boundary UAV are stepped by a small launch on
+  // `stream`, followed there by the collective, while the interior launch runs on `stream2` and never waits for a collective
+  bool      shard_split = true;     // tuning: MRS_SHARD_SPLIT=0 keeps every tick in the serial form (fused launch, then the collective)
+  int       split_min_blocks = 512; // tuning / tests: MRS_SHARD_SPLIT_MIN_BLOCKS
+  uint32_t  x_nbnd = 0;             // boundary blocks of this rank as of the last search
+  double    x_dt = -1.0;            // dt of the previous call: the announcements of its last launches assumed it
+  bool      rpm_over = false;       // some motor speed was set beyond its airframe's max_rpm: the displacement bound does not hold
+  int64_t   x_split_ticks = 0;
+  // test hook (mrs_swarm_debug_chaos): this rank's host sleeps a random time before every launch of a sharded tick and, half of
+  // the time, decides on the stall / warning words as it read them one launch earlier (still within what the protocol guarantees)
+  int       chaos_max_us = 0;
+  uint64_t  chaos_state = 0x9E3779B97F4A7C15ull;
+  unsigned  chaos_T = 0, chaos_W = 0;
   double*   dS = nullptr;
   uint32_t* dF = nullptr;
   TypeParams* dT = nullptr;
@@ -711,6 +730,8 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = getenv("MRS_SHARD_SPLIT")) s->shard_split = atoi(e) != 0;
+  if (const char* e = getenv("MRS_SHARD_SPLIT_MIN_BLOCKS")) s->split_min_blocks = atoi(e) > 0 ? atoi(e) : 1;
   HIPCHK(hipMalloc(&s->dS, sizeof(double) * (size_t)F_COUNT * s->npad));
   HIPCHK(hipMalloc(&s->dF, sizeof(uint32_t) * (size_t)s->npad));
   HIPCHK(hipMalloc(&s->dDiag, sizeof(unsigned long long) * 4));
@@ -1105,9 +1126,20 @@ static bool fused_usable(const mrs_swarm* s) {
 // MRS_PROGRESS_TIMEOUT_S seconds (default 30; a wedged kernel, a collective whose peer is gone) is an error, returned with the words
 // the host last saw — after it the swarm's stream, and for a sharded swarm its communicator, must be considered dead: destroy the
 // swarm from a fresh process (never re-exec a process that has touched the GPU).
+// the stall / warning index the host knows of: each chain of a split tick keeps mirrors of its own (one writer per word)
+static inline unsigned min_nonzero(unsigned a, unsigned b) { return a == 0u ? b : (b == 0u ? a : (a < b ? a : b)); }
+static inline unsigned stall_word(const volatile unsigned* hw) { return min_nonzero(hw[CTL_STALL], hw[CTL_STALL2]); }
+static inline unsigned warn_word(const volatile unsigned* hw) { return min_nonzero(hw[CTL_WARN], hw[CTL_WARN2]); }
+
 static int wait_for_progress(mrs_swarm* s, const volatile unsigned* hw, unsigned index, int lead) {
   if (!hw) return MRS_OK;
-  auto behind = [&]() { return (int)(index - hw[CTL_PROGRESS]) > lead && hw[CTL_STALL] == 0u; };
+  // (launches after a stall index T are no-ops and report no progress: once launch T has started nothing more will come.  A sharded
+  //  swarm ANNOUNCES stall indices ahead of time, so a known T does not end the waiting by itself — an earlier one may still turn up,
+  //  and the host must not outrun what it has seen)
+  auto behind = [&]() {
+    const unsigned T = stall_word(hw), P = hw[CTL_PROGRESS];
+    return (int)(index - P) > lead && !(T != 0u && P >= T);
+  };
   if (!behind()) return MRS_OK;
   static const double limit_s = getenv("MRS_PROGRESS_TIMEOUT_S") ? atof(getenv("MRS_PROGRESS_TIMEOUT_S")) : 30.0;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1118,8 +1150,8 @@ static int wait_for_progress(mrs_swarm* s, const volatile unsigned* hw, unsigned
     if (q != hipSuccess && q != hipErrorNotReady) return fail(MRS_ERR_HIP, std::string("fused launches: ") + hipGetErrorString(q));
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
       return fail(MRS_ERR_HIP, "the device made no progress for " + std::to_string((int)limit_s) + " s: waiting for launch " + std::to_string(index - (unsigned)lead) +
-                                   ", progress word " + std::to_string(hw[CTL_PROGRESS]) + ", stall word " + std::to_string(hw[CTL_STALL]) + ", warning word " +
-                                   std::to_string(hw[CTL_WARN]) + " (the stream" + (s->comm_world > 1 ? " and the communicator are" : " is") + " dead: use a fresh process)");
+                                   ", progress word " + std::to_string(hw[CTL_PROGRESS]) + ", stall word " + std::to_string(stall_word(hw)) + ", warning word " +
+                                   std::to_string(warn_word(hw)) + " (the stream" + (s->comm_world > 1 ? " and the communicator are" : " is") + " dead: use a fresh process)");
   }
   return MRS_OK;
 }
@@ -1151,9 +1183,9 @@ static int launch_fused(mrs_swarm* s, const mrs_swarm::TickRec& e) {
     HIPCHK(hipEventRecord(e0, s->stream));
   }
   if (s->arith == MRS_ARITH_FAST)
-    HIPCHK(mrs_launch_step_coll_fast(v, cd, e.dt, variant, s->stream));
+    HIPCHK(mrs_launch_step_coll_fast(v, cd, e.dt, variant, 0, s->stream));
   else
-    HIPCHK(mrs_launch_step_coll_literal(v, cd, e.dt, variant, s->stream));
+    HIPCHK(mrs_launch_step_coll_literal(v, cd, e.dt, variant, 0, s->stream));
   if (s->profiling == 2) HIPCHK(hipEventRecord(e1, s->stream));
   mrs_swarm::TickRec rec = e;
   rec.pin = mrs_collide_fused_pin(s->cwork);
@@ -1443,6 +1475,14 @@ struct mrs_loopback_group {
   std::vector<hipEvent_t>  ev_ready, ev_copied;
   std::vector<int>         device;
   std::atomic<int>         failed{0};
+  // rendezvous mode (mrs_loopback_group_set_rendezvous): no barrier — a rank stages its block, publishes the index of the collective
+  // and only waits until every peer has published the same index (it cannot enqueue copies of data a peer has not enqueued yet);
+  // staging buffers and events alternate between two sets, so a fast rank never waits for a slow one to have COPIED
+  int                                     rendezvous = 0;
+  std::unique_ptr<std::atomic<unsigned>[]> seq;           // seq[q] = collectives rank q has published
+  std::vector<void*>                      stage[2];
+  std::vector<size_t>                     stage_cap[2];
+  std::vector<hipEvent_t>                 ev_ready2[2], ev_copied2[2];
   void barrier() {  // sense-reversing spin barrier (at most a handful of threads, all inside the same library call)
     const unsigned gen = generation.load(std::memory_order_acquire);
     if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
@@ -1466,20 +1506,71 @@ struct mrs_loopback_group {
 namespace {
 // all-gather among the swarms of a loopback group: every rank copies every rank's send buffer into its own receive buffer, device
 // to device on its own stream; events order the copies behind the producers and the producers' next writes behind the copies
+int loopback_allgather_rendezvous(mrs_loopback_group* g, int rank, const void* send, void* recv, size_t bytes, hipStream_t st) {
+  const size_t   r = (size_t)rank;
+  const unsigned k = g->seq[r].load(std::memory_order_relaxed);  // index of this collective (only this thread writes seq[rank])
+  const int      par = (int)(k & 1u);
+  hipError_t     e = hipSuccess;
+  // the staging buffer of this parity was last read by the peers in collective k - 2: their "copied" events were recorded before they
+  // published k - 1, which this rank waited for in collective k - 1
+  for (int q = 0; q < g->world && e == hipSuccess && k >= 2u; q++) e = hipStreamWaitEvent(st, g->ev_copied2[par][(size_t)q], 0);
+  if (e == hipSuccess && bytes > g->stage_cap[par][r]) {
+    e = hipStreamSynchronize(st);
+    if (g->stage[par][r]) (void)hipFree(g->stage[par][r]);
+    g->stage[par][r] = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&g->stage[par][r], bytes);
+    g->stage_cap[par][r] = e == hipSuccess ? bytes : 0;
+  }
+  if (e == hipSuccess && bytes) e = hipMemcpyAsync(g->stage[par][r], send, bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipEventRecord(g->ev_ready2[par][r], st);
+  if (e != hipSuccess) g->failed.store(1);
+  g->seq[r].store(k + 1u, std::memory_order_release);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int q = 0; q < g->world; q++) {
+    unsigned long spins = 0;
+    while (g->seq[(size_t)q].load(std::memory_order_acquire) < k + 1u) {
+      if (++spins > 2000) std::this_thread::yield();
+      if ((spins & 0xFFFF) == 0 && (g->failed.load() || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))) {
+        g->failed.store(1);
+        return fail(MRS_ERR_HIP, "loopback all-gather (rendezvous): a peer never arrived at collective " + std::to_string(k));
+      }
+    }
+  }
+  for (int q = 0; q < g->world && e == hipSuccess; q++) {
+    e = hipStreamWaitEvent(st, g->ev_ready2[par][(size_t)q], 0);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->stage[par][(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
+  }
+  if (e == hipSuccess) e = hipEventRecord(g->ev_copied2[par][r], st);
+  if (e != hipSuccess || g->failed.load()) {
+    g->failed.store(1);
+    return fail(MRS_ERR_HIP, std::string("loopback all-gather (rendezvous): ") + hipGetErrorString(e));
+  }
+  return MRS_OK;
+}
+
 int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* recv, size_t bytes, hipStream_t st) {
-  hipError_t e = hipEventRecord(g->ev_ready[(size_t)rank], st);
+  if (g->rendezvous) return loopback_allgather_rendezvous(g, rank, send, recv, bytes, st);
+  const char* what = "record";
+  hipError_t  e = hipGetLastError();  // (an error left behind by an earlier asynchronous launch belongs to that launch, not to this collective)
+  if (e != hipSuccess) what = "an earlier launch on this thread";
+  if (e == hipSuccess) e = hipEventRecord(g->ev_ready[(size_t)rank], st);
   g->send[(size_t)rank] = send;
   if (e != hipSuccess) g->failed.store(1);
   g->barrier();  // every rank has published its buffer and recorded "my send data is complete"
   for (int q = 0; q < g->world && e == hipSuccess; q++) {
+    what = "wait for a peer's data";
     e = hipStreamWaitEvent(st, g->ev_ready[(size_t)q], 0);
-    if (e == hipSuccess && bytes) e = hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->send[(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && bytes) {
+      what = "copy";
+      e = hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->send[(size_t)q], bytes, hipMemcpyDeviceToDevice, st);
+    }
   }
   if (e == hipSuccess) e = hipEventRecord(g->ev_copied[(size_t)rank], st);
   if (e != hipSuccess) g->failed.store(1);
   g->barrier();  // every rank has enqueued its copies
   for (int q = 0; q < g->world && e == hipSuccess; q++) e = hipStreamWaitEvent(st, g->ev_copied[(size_t)q], 0);  // nobody overwrites a buffer a peer still reads
-  if (e != hipSuccess || g->failed.load()) return fail(MRS_ERR_HIP, std::string("loopback all-gather: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("loopback all-gather (") + what + ", " + std::to_string(bytes) + " bytes per rank): " + hipGetErrorString(e));
+  if (g->failed.load()) return fail(MRS_ERR_HIP, "loopback all-gather: a peer of the group has failed");
   return MRS_OK;
 }
 
@@ -1552,7 +1643,23 @@ int mrs_loopback_group_create(int32_t world, mrs_loopback_group_t** out) {
   g->ev_ready.assign((size_t)world, nullptr);
   g->ev_copied.assign((size_t)world, nullptr);
   g->device.assign((size_t)world, -1);
+  g->seq.reset(new std::atomic<unsigned>[(size_t)world]);
+  for (int q = 0; q < world; q++) g->seq[(size_t)q].store(0u);
+  for (int par = 0; par < 2; par++) {
+    g->stage[par].assign((size_t)world, nullptr);
+    g->stage_cap[par].assign((size_t)world, 0);
+    g->ev_ready2[par].assign((size_t)world, nullptr);
+    g->ev_copied2[par].assign((size_t)world, nullptr);
+  }
   *out = g;
+  return MRS_OK;
+}
+
+int mrs_loopback_group_set_rendezvous(mrs_loopback_group_t* g, int32_t on) {
+  if (!g) return fail(MRS_ERR_ARG, "null group");
+  for (int q = 0; q < g->world; q++)
+    if (g->seq[(size_t)q].load() != 0u) return fail(MRS_ERR_ARG, "the mode of a loopback group is chosen before its first collective");
+  g->rendezvous = on ? 1 : 0;
   return MRS_OK;
 }
 
@@ -1562,6 +1669,11 @@ int mrs_loopback_group_destroy(mrs_loopback_group_t* g) {
     if (g->device[(size_t)q] >= 0) (void)hipSetDevice(g->device[(size_t)q]);
     if (g->ev_ready[(size_t)q]) (void)hipEventDestroy(g->ev_ready[(size_t)q]);
     if (g->ev_copied[(size_t)q]) (void)hipEventDestroy(g->ev_copied[(size_t)q]);
+    for (int par = 0; par < 2; par++) {
+      if (g->ev_ready2[par][(size_t)q]) (void)hipEventDestroy(g->ev_ready2[par][(size_t)q]);
+      if (g->ev_copied2[par][(size_t)q]) (void)hipEventDestroy(g->ev_copied2[par][(size_t)q]);
+      if (g->stage[par][(size_t)q]) (void)hipFree(g->stage[par][(size_t)q]);
+    }
   }
   delete g;
   return MRS_OK;
@@ -1576,9 +1688,38 @@ int mrs_swarm_comm_init_loopback(mrs_swarm_t* s, mrs_loopback_group_t* g, int32_
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipEventCreateWithFlags(&g->ev_ready[(size_t)rank], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&g->ev_copied[(size_t)rank], hipEventDisableTiming));
+  for (int par = 0; par < 2; par++) {
+    HIPCHK(hipEventCreateWithFlags(&g->ev_ready2[par][(size_t)rank], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&g->ev_copied2[par][(size_t)rank], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(g->ev_copied2[par][(size_t)rank], s->stream));  // (an event that was never recorded must not be waited for)
+  }
   g->device[(size_t)rank] = s->device;
   s->comm_group           = g;
   return comm_buffers(s, g->world, rank, n_total);
+}
+
+int mrs_swarm_get_split_stats(mrs_swarm_t* s, int64_t* split_ticks, int64_t* boundary_blocks) {
+  MRS_LOCK(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (split_ticks) *split_ticks = s->x_split_ticks;
+  if (boundary_blocks) *boundary_blocks = (int64_t)s->x_nbnd;
+  return MRS_OK;
+}
+
+extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microseconds);
+int mrs_debug_stream_delay(void* stream, double microseconds) {
+  if (!(microseconds >= 0) || microseconds > 1e6) return fail(MRS_ERR_ARG, "bad delay");
+  HIPCHK(mrs_launch_stream_delay((hipStream_t)stream, microseconds));
+  return MRS_OK;
+}
+
+int mrs_swarm_debug_chaos(mrs_swarm_t* s, int32_t max_sleep_us, uint64_t seed) {
+  MRS_LOCK(s);
+  if (!s || max_sleep_us < 0) return fail(MRS_ERR_ARG, "bad chaos arguments");
+  s->chaos_max_us = max_sleep_us;
+  s->chaos_state  = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  if (s->chaos_state == 0) s->chaos_state = 1;
+  return MRS_OK;
 }
 
 int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange) {
@@ -1710,7 +1851,10 @@ int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
   std::vector<unsigned> heads((size_t)world * 2);
   HIPCHK(hipMemcpy2DAsync(heads.data(), 2 * sizeof(unsigned), s->x_map_recv, sizeof(uint32_t) * (size_t)stride, 2 * sizeof(unsigned), (size_t)world,
                           hipMemcpyDeviceToHost, s->stream));
+  unsigned nbnd = 0;
+  if (s->n > 0) HIPCHK(hipMemcpyAsync(&nbnd, mrs_collide_ctl_words(s->cwork) + CTL_NBND, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+  s->x_nbnd = nbnd;
   long long need = 0;
   for (int q = 0; q < world; q++) {
     if ((long long)heads[(size_t)q * 2] > need) need = heads[(size_t)q * 2];
@@ -1738,12 +1882,13 @@ int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval)
     CollDev  cd;
     SwarmDev v = s->view();
     HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
+    mrs_collide_export_part(&cd, MRS_PART_FULL, 0u, 0u, dt, s->rpm_over ? 0 : 1);
     s->region_launches++;
     const int variant = s->n_cascade > 0 ? 0 : 1;
     if (s->arith == MRS_ARITH_FAST)
-      HIPCHK(mrs_launch_step_coll_fast(v, cd, dt, variant, s->stream));
+      HIPCHK(mrs_launch_step_coll_fast(v, cd, dt, variant, 0, s->stream));
     else
-      HIPCHK(mrs_launch_step_coll_literal(v, cd, dt, variant, s->stream));
+      HIPCHK(mrs_launch_step_coll_literal(v, cd, dt, variant, 0, s->stream));
     mrs_collide_fused_advance(s->cwork);
   } else {
     HIPCHK(mrs_collide_export_fold_stall(s->cwork, s->tau + 1, s->stream));  // a rank without UAVs still watches the headers
@@ -1751,6 +1896,36 @@ int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval)
   s->tau++;
   const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
   return comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
+}
+
+// One tick of the export-set exchange in the SPLIT form: the boundary launch (the blocks that hold a UAV with a foreign partner; it
+// evaluates, steps, writes this rank's export block) and the collective on `stream`, the interior launch on `stream2`.  The two
+// chains meet inside the kernels (per-block epoch words: step_device.inc), never on the host and never through an event, so the
+// interior launch of tick t+1 runs beside the collective of tick t.  `split_base`: launch index behind which this run of split
+// ticks started (mrs_collide_handoff_init).
+int launch_split_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval, unsigned split_base) {
+  CollDev  cd, part;
+  SwarmDev v = s->view();
+  HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
+  s->region_launches++;
+  const int      variant = s->n_cascade > 0 ? 0 : 1, bound_ok = s->rpm_over ? 0 : 1;
+  const unsigned grid_b  = s->x_nbnd > 0 ? s->x_nbnd : 1u;
+  auto launch = [&](const CollDev& c, int grid, hipStream_t st) {
+    return s->arith == MRS_ARITH_FAST ? mrs_launch_step_coll_fast(v, c, dt, variant, grid, st) : mrs_launch_step_coll_literal(v, c, dt, variant, grid, st);
+  };
+  part = cd;
+  mrs_collide_export_part(&part, MRS_PART_BOUNDARY, s->x_nbnd, (s->tau + 1u - split_base) * grid_b, dt, bound_ok);
+  HIPCHK(launch(part, (int)grid_b, s->stream));
+  const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
+  int rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
+  if (rc) return rc;
+  part = cd;
+  mrs_collide_export_part(&part, MRS_PART_INTERIOR, s->x_nbnd, 0u, dt, bound_ok);
+  HIPCHK(launch(part, 0, s->stream2));
+  mrs_collide_fused_advance(s->cwork);
+  s->tau++;
+  s->x_split_ticks++;
+  return MRS_OK;
 }
 
 // Ticks of the export-set exchange.  All ranks must issue the same launches and collectives in the same order, yet nobody may wait
@@ -1767,7 +1942,20 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   bool pending = false;  // the collision tick after the most recent step has not been evaluated yet
   s->p_valid = false;    // (single-GPU lazies do not mix with this path)
   s->fk_ok   = false;
-  const unsigned lead = (unsigned)(s->fused_lead > 0 ? s->fused_lead : 1), search_ahead = lead + 3;
+  // Split ticks (see launch_split_export; the protocol and its proof obligations: DESIGN §5).  In the split form a launch does not
+  // see the reports the collective of the previous tick carries, so a stall index T must be ANNOUNCED MRS_PRED_HORIZON launches
+  // ahead (displacement bound, step_device.inc) — and the ticks the bound cannot vouch for run in the serial form, whose launches
+  // test exactly and hear of each other's reports through the collective in stream order: the first MRS_PRED_HORIZON ticks of
+  // every call (the host may have written positions, velocities or airframe constants since the last one) and after every search.
+  const bool protocol_split = s->shard_split;  // (the same on every rank: it sets how long a report takes to reach everybody)
+  const unsigned lead = (unsigned)(s->fused_lead > 0 ? s->fused_lead : 1), search_ahead = lead + (protocol_split ? 6u : 3u);
+  int serial_left = (int)MRS_PRED_HORIZON;
+  if (dt != s->x_dt) s->x_ok = false;  // the announcements of the last call's final launches assumed its dt: start from a search
+  s->x_dt = dt;
+  const int nb = (s->n + 63) / 64;
+  auto split_ok = [&]() {
+    return protocol_split && s->n > 0 && nb >= s->split_min_blocks && (long long)s->x_nbnd * 4 <= nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
+  };
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
       const int k = n_ticks - done < s->x_fallback_left ? n_ticks - done : s->x_fallback_left;
@@ -1784,6 +1972,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       s->x_ticks++;
       done++;
       pending = false;
+      serial_left = (int)MRS_PRED_HORIZON;
       if (incomplete) s->x_fallback_left = 64;
       continue;
     }
@@ -1793,21 +1982,58 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     const unsigned first = s->tau + 1;                                 // launch indices run on from the last search
     unsigned       last  = s->tau + (unsigned)(n_ticks - done);       // ... to the end of the call, unless a word says otherwise
     mrs_swarm::Collide off;
+    bool     in_split   = false;
+    unsigned split_base = 0;
+    s->chaos_T = s->chaos_W = 0u;
     while (s->tau < last) {
       const unsigned next = s->tau + 1;
       // (a device that makes no progress is an ERROR here, never a reason to launch anyway: lock-step of the ranks rests on every host
       //  having seen the words of launch next - lead - 1 before it issues launch `next`)
       if ((rc = wait_for_progress(s, hw, next, (int)lead))) return rc;
-      const unsigned T = hw[CTL_STALL], W = hw[CTL_WARN];
+      unsigned T = stall_word(hw), W = warn_word(hw);
+      if (s->chaos_max_us > 0) {
+        s->chaos_state ^= s->chaos_state << 13; s->chaos_state ^= s->chaos_state >> 7; s->chaos_state ^= s->chaos_state << 17;
+        const unsigned Tf = T, Wf = W;
+        if (s->chaos_state & 0x100u) { T = s->chaos_T; W = s->chaos_W; }
+        s->chaos_T = Tf; s->chaos_W = Wf;
+        usleep((useconds_t)((s->chaos_state >> 16) % (uint64_t)(s->chaos_max_us + 1)));
+      }
       if (T != 0u && T + lead + 1 < last) last = T + lead + 1;
       if (W != 0u && W + search_ahead - 1 < last) last = W + search_ahead - 1;
       if (next > last) break;
-      if ((rc = launch_fused_export(s, dt, pending ? c : off))) return rc;
+      if (serial_left == 0 && !in_split && split_ok() && last - s->tau >= 4u) {
+        // from the serial form to the split one: what the last collective carried is folded into the control words (the first
+        // interior launch reads nothing else), every block counts as finished by launch tau, and the second stream starts behind all that
+        HIPCHK(mrs_collide_export_fold_stall(s->cwork, 0u, s->stream));
+        HIPCHK(mrs_collide_handoff_init(s->cwork, s->n, s->tau, s->stream));
+        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+        in_split   = true;
+        split_base = s->tau;
+      }
+      if (in_split) {
+        if ((rc = launch_split_export(s, dt, pending ? c : off, split_base))) return rc;
+      } else {
+        if ((rc = launch_fused_export(s, dt, pending ? c : off))) return rc;
+        if (serial_left > 0) serial_left--;
+      }
       pending = true;
+    }
+    if (in_split) {  // back to one stream: everything that follows (fold, search, the caller's work) comes behind the interior launches too
+      HIPCHK(hipEventRecord(s->ev_join, s->stream2));
+      HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    }
+    if (protocol_split) {
+      // What a rank's interior launches reported in the last ticks of the segment has not travelled yet (it rides with the boundary
+      // launch two ticks on): one more exchange of the export blocks, headers brought up to date, so that every rank ends the
+      // segment with the same words.  (All ranks do this, whichever form their own ticks took.)
+      HIPCHK(mrs_collide_export_header_refresh(s->cwork, s->stream));
+      const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
+      if ((rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes))) return rc;
     }
     HIPCHK(mrs_collide_export_fold_stall(s->cwork, 0u, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    const unsigned T = hw[CTL_STALL], W = hw[CTL_WARN];  // identical on every rank
+    const unsigned T = stall_word(hw), W = warn_word(hw);  // identical on every rank
     const unsigned launched = s->tau + 1 - first;
     const unsigned ran = (T != 0u && T + 1 >= first && T + 1 - first < launched) ? T + 1 - first : launched;
     done += (int)ran;
@@ -1820,6 +2046,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       int incomplete = 0;
       if ((rc = export_search(s, c, &incomplete))) return rc;
       pending = false;
+      serial_left = (int)MRS_PRED_HORIZON;
       if (incomplete) s->x_fallback_left = 64;
     }
   }
@@ -1830,9 +2057,11 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     cd.p_out = nullptr;
     HIPCHK(mrs_collide_export_eval(v, cd, s->stream));
   }
-  unsigned w[8];
+  unsigned w[CTL_WORDS];
   HIPCHK(mrs_collide_fused_words(s->cwork, s->stream, w));
   if (w[CTL_BADSLOT]) return fail(MRS_ERR_HIP, "export-set exchange: a listed foreign UAV is not in its owner's export set (" + std::to_string(w[CTL_BADSLOT]) + " entries)");
+  if (w[CTL_ERROR] & 1u) return fail(MRS_ERR_HIP, "split sharded tick: a launch waited in vain for the launch on the other stream (the results of this call are not valid; the stream and the communicator are dead: use a fresh process)");
+  if (w[CTL_ERROR] & 2u) return fail(MRS_ERR_HIP, "split sharded tick: a UAV left its skin without the displacement bound announcing it (DESIGN §5) — the results of this call are not valid; run with MRS_SHARD_SPLIT=0 on every rank and report the case");
   return MRS_OK;
 }
 }  // namespace
@@ -1939,8 +2168,12 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
       for (int j = 0; j < it.w; j++) {
         if (it.f == F_RPM) {  // state_.motor_rpm has n_motors entries: columns beyond a UAV's motor count stay zero
           s->stage.resize((size_t)count);
-          for (int k = 0; k < count; k++)
-            s->stage[(size_t)k] = j < s->keys[s->uav_type[(size_t)first + k]].mp.n_motors ? it.p[(size_t)k * it.w + j] : 0.0;
+          for (int k = 0; k < count; k++) {
+            const mrs_model_params_t& mp = s->keys[s->uav_type[(size_t)first + k]].mp;
+            s->stage[(size_t)k] = j < mp.n_motors ? it.p[(size_t)k * it.w + j] : 0.0;
+            // (the motor low-pass keeps |rpm| <= max_rpm once it is: the thrust cap of the sharded tick's displacement bound rests on that)
+            if (!(fabs(s->stage[(size_t)k]) <= mp.max_rpm)) s->rpm_over = true;
+          }
           if ((rc = put_column(s, it.f + j, first, count, s->stage.data()))) return rc;
         } else if ((rc = put_strided(s, it.f + j, first, count, it.p, it.w, j))) {
           return rc;

@@ -126,6 +126,7 @@ enum {
   CTL_DONE_B = 9,    // tick index of the last boundary launch all of whose blocks have finished
   CTL_TICKET_B = 10, // arrivals of boundary-launch blocks (cumulative since the hand-off words were last reset)
   CTL_NBND = 11,     // 64-UAV blocks of this rank that hold a boundary UAV (set by the search)
+  CTL_DONE_I0 = 12,  // tick index of the last interior launch whose first block has finished (so the launch before it is complete)
   CTL_WORDS = 16
 };
 // class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)
@@ -157,5 +158,6 @@ struct CollDev {
   const uint32_t*     blk_list;   // [n_bnd]
   uint32_t*           epoch;      // [blocks]
   uint32_t            ticket_target, n_bnd;
-  double              pred_hdt;   // horizon * dt
+  double              pred_hdt;   // horizon * dt (+inf: the bound cannot be given for this swarm — every tick announces)
+  double              pred_lim;   // sqrt(lim2)
 };

@@ -96,6 +96,7 @@ ABI_SYMBOLS = [
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
     "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component", "mrs_debug_pid_update", "mrs_swarm_set_state_pos", "mrs_swarm_set_pid", "mrs_swarm_clone",
+    "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -171,6 +172,10 @@ class LoopbackGroup:
         self._h = C.c_void_p()
         self.world = int(world)
         _check(_lib.mrs_loopback_group_create(self.world, C.byref(self._h)))
+
+    def set_rendezvous(self, on=True):
+        """the all-gather without host barriers: a rank waits only for its peers to ARRIVE at the same collective"""
+        _check(_lib.mrs_loopback_group_set_rendezvous(self._h, int(bool(on))))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -248,6 +253,10 @@ def load_library():
         "mrs_loopback_group_create": [i32, C.POINTER(vp)],
         "mrs_loopback_group_destroy": [vp],
         "mrs_swarm_comm_init_loopback": [vp, vp, i32, C.c_int64],
+        "mrs_loopback_group_set_rendezvous": [vp, i32],
+        "mrs_swarm_debug_chaos": [vp, i32, C.c_uint64],
+        "mrs_swarm_get_split_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+        "mrs_debug_stream_delay": [vp, C.c_double],
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
@@ -464,6 +473,14 @@ class Swarm:
         d["parallelism"] = (f"{d['world']} equal-count shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, "
                             + ("RCCL" if d["rccl_ranks"] else "in-process / caller-supplied collective"))
         return d
+
+    def debug_chaos(self, max_sleep_us, seed=1):
+        _check(_lib.mrs_swarm_debug_chaos(self._h, int(max_sleep_us), int(seed)))
+
+    def split_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(_lib.mrs_swarm_get_split_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def comm_init_loopback(self, group, rank, n_total):
         _check(_lib.mrs_swarm_comm_init_loopback(self._h, group._h, int(rank), int(n_total)))

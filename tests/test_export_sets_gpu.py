@@ -35,9 +35,11 @@ def run_ranks(fns):
     for t in th:
         t.join(300)
     assert not any(t.is_alive() for t in th), "a rank hangs in a collective"
-    for e in errs:
-        if e is not None:
-            raise e
+    # the rank that failed first makes its peers fail in the group's all-gather: report the cause, not the echo
+    real = [e for e in errs if e is not None and "loopback all-gather" not in str(e)]
+    seen = [e for e in errs if e is not None]
+    if seen:
+        raise (real + seen)[0] from RuntimeError(" | ".join(f"rank {k}: {e}" for k, e in enumerate(errs) if e is not None))
 
 
 class VirtualShards:
