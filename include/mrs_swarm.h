@@ -260,6 +260,11 @@ int mrs_swarm_get_split_stats(mrs_swarm_t* s, int64_t* split_ticks, int64_t* bou
 /* test / measurement hook: a kernel that keeps `stream` (a hipStream_t of this process) busy for `microseconds` — stands in for the
  * latency of a collective in tools/sharded_rank_cost.py */
 int mrs_debug_stream_delay(void* stream, double microseconds);
+/* measurement stand-in for ONE rank of a `world`-rank sharded swarm alone on a device (tools/sharded_rank_cost.py): every collective
+ * takes `collective_latency_us` of stream time, and the rank's neighbours in the slab order are periodic images of itself
+ * `slab_width` metres away — boundary sets, launches and buffer sizes of the real run, none of its physics across the slab faces.
+ * Not a simulation backend. */
+int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, double collective_latency_us, double slab_width);
 int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange);
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
 int mrs_swarm_comm_destroy(mrs_swarm_t* s);

@@ -1096,22 +1096,11 @@ __global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_c
   if (l1) atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1);
 }
 
-// header of this rank's export block := the smallest stall / warning index the rank knows of (end of a segment of ticks: what its
-// interior launches reported last has not travelled yet)
-__global__ void k_header_refresh(Pos4* send, const uint32_t* fctl) {
-  send[0].w = (double)fctl[CTL_STALL];
-  send[0].z = (double)fctl[CTL_WARN];
-}
-
 // start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet
 __global__ void k_handoff_init(uint32_t* fctl, uint32_t* epoch, int n_blocks, uint32_t tau) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < n_blocks) epoch[b] = tau;
-  if (b == 0) {
-    fctl[CTL_DONE_B]   = tau;
-    fctl[CTL_DONE_I0]  = tau;
-    fctl[CTL_TICKET_B] = 0u;
-  }
+  if (b == 0) fctl[CTL_I_STARTED] = tau;
 }
 
 __global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint32_t* ctl) {
@@ -1183,16 +1172,17 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
 // the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
 // batch of ticks, whose last launch nobody has looked behind yet
 // progress_tau != 0: also stands in for the fused launch of a rank that holds no UAVs (it reports progress and the warning word)
-__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, uint32_t* fctl, volatile uint32_t* hostw, uint32_t progress_tau) {
-  uint32_t stall = fctl[CTL_STALL], warn = fctl[CTL_WARN];
+__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_send, volatile uint32_t* hostw, uint32_t progress_tau) {
+  uint32_t* own   = (uint32_t*)x_send;  // the rank's own header words (MRS_HDR_*): what it knows, what its next collective carries
+  uint32_t  stall = own[MRS_HDR_STALL], warn = own[MRS_HDR_WARN];
   for (int q = 0; q < world; q++) {
-    const Pos4     hd = x_recv[(size_t)q * (size_t)block];
-    const uint32_t h = (uint32_t)hd.w, wq = (uint32_t)hd.z;
+    const uint32_t* hq = (const uint32_t*)(x_recv + (size_t)q * (size_t)block);
+    const uint32_t  h = hq[MRS_HDR_STALL], wq = hq[MRS_HDR_WARN];
     if (h != 0u && (stall == 0u || h < stall)) stall = h;
     if (wq != 0u && (warn == 0u || wq < warn)) warn = wq;
   }
-  fctl[CTL_STALL] = stall;
-  fctl[CTL_WARN]  = warn;
+  own[MRS_HDR_STALL] = stall;
+  own[MRS_HDR_WARN]  = warn;
   __hip_atomic_store(&hostw[CTL_STALL], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&hostw[CTL_WARN], warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&hostw[CTL_STALL2], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (nothing else runs: both chains' mirrors agree)
@@ -1250,6 +1240,48 @@ __global__ void k_stream_delay(long long ticks) {
   while (wall_clock64() - t0 < ticks && k < 400000000u) k++;
 }
 }  // namespace
+namespace {
+// The collective of the measurement stand-in as ONE kernel that lasts `ticks` of the 100 MHz clock (one wave watches it — a real
+// collective keeps a few waves busy, not the chip): the rank's own block of `bytes` bytes is copied to the places
+// of ranks rank-1, rank, rank+1 of `recv`; when the blocks are 48-byte records (`records`), absent ranks read as NaN records and the
+// two images are moved one slab width to either side.
+__global__ void k_standin_gather(const uint4* send, uint4* recv, long long vec_per_rank, int rank, int world, int records, double width, long long ticks) {
+  const long long t_start = wall_clock64();
+  const long long total = vec_per_rank * (long long)world;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long long)gridDim.x * blockDim.x) {
+    const int       q = (int)(v / vec_per_rank);
+    const long long j = v - (long long)q * vec_per_rank;
+    const int       d = q - rank;
+    if (d < -1 || d > 1) {
+      if (records) recv[v] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      continue;
+    }
+    uint4 x = send[j];
+    if (records && d != 0 && j % 3 == 0) {  // a 48-byte record = three 16-byte vectors; the first holds x and y
+      double px = __builtin_bit_cast(double, make_uint2(x.x, x.y));
+      px += (double)d * width;
+      const uint2 b = __builtin_bit_cast(uint2, px);
+      x.x = b.x; x.y = b.y;
+    }
+    recv[v] = x;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {  // ONE wave keeps the kernel alive until the collective's latency is over
+    unsigned k = 0;
+    while (wall_clock64() - t_start < ticks && k < 400000000u) k++;
+  }
+}
+}  // namespace
+extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int records, double width,
+                                                hipStream_t st) {
+  if (bytes % 16 != 0) return hipErrorInvalidValue;
+  const long long vec = (long long)(bytes / 16);
+  long long       blocks = (vec * world + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_standin_gather, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)send, (uint4*)recv, vec, rank, world, records, width,
+                     (long long)(latency_us * 100.0));
+  return hipGetLastError();
+}
 extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microseconds) {
   hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, st, (long long)(microseconds * 100.0));
   return hipGetLastError();
@@ -1322,18 +1354,11 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   return hipSuccess;
 }
 
-// the part of a split tick this launch is (MRS_PART_*), the arrivals that complete a boundary launch, the step of the displacement bound
-extern "C" void mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, unsigned ticket_target, double dt, int bound_ok) {
+// the part of a split tick this launch is (MRS_PART_*) and the step of the displacement bound
+extern "C" void mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int bound_ok) {
   cd->part          = part;
   cd->n_bnd         = n_bnd;
-  cd->ticket_target = ticket_target;
   cd->pred_hdt      = bound_ok ? (double)MRS_PRED_HORIZON * dt : INFINITY;
-}
-
-extern "C" hipError_t mrs_collide_export_header_refresh(CollideWork* w, hipStream_t st) {
-  if (!w || !w->x_send || !w->fctl) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_header_refresh, dim3(1), dim3(1), 0, st, w->x_send, w->fctl);
-  return hipGetLastError();
 }
 
 // a run of split ticks starts behind launch `tau` (everything before it has completed in stream order)
@@ -1364,7 +1389,7 @@ extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int p
 extern "C" int mrs_collide_fused_pin(const CollideWork* w) { return w ? w->pcur : 0; }
 
 extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, unsigned progress_tau, hipStream_t st) {
-  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->fctl, w->hostw, progress_tau);
+  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->x_send, w->hostw, progress_tau);
   return hipGetLastError();
 }
 

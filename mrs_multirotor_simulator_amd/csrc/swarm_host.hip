@@ -65,10 +65,9 @@ extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t 
 extern "C" void mrs_collide_free(CollideWork* w);
 extern "C" hipError_t mrs_launch_step_coll_literal(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
 extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
-extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, unsigned ticket_target, double dt, int bound_ok);
+extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int bound_ok);
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
-extern "C" hipError_t mrs_collide_export_header_refresh(CollideWork* w, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
@@ -314,6 +313,10 @@ struct mrs_swarm {
   mrs_allgather_fn      comm_fn = nullptr;
   void*                 comm_user = nullptr;
   mrs_loopback_group_t* comm_group = nullptr;
+  // measurement stand-in (mrs_swarm_comm_init_standin): ONE rank of `world` alone on the device; its neighbours in the slab order
+  // are images of itself one slab width away, and every collective costs a fixed latency
+  bool   comm_standin = false;
+  double standin_delay_us = 0.0, standin_width = 0.0;
   // export-set exchange: between two searches only boundary UAVs travel
   int       exchange = MRS_EXCHANGE_EXPORT_SETS;
   bool      x_ok = false;           // export lists are live: the next tick can be a fused launch + export-set all-gather
@@ -327,6 +330,7 @@ struct mrs_swarm {
   // `stream`, followed there by the collective, while the interior launch runs on `stream2` and never waits for a collective
   bool      shard_split = true;     // tuning: MRS_SHARD_SPLIT=0 keeps every tick in the serial form (fused launch, then the collective)
   int       split_min_blocks = 512; // tuning / tests: MRS_SHARD_SPLIT_MIN_BLOCKS
+  double    split_max_fraction = 0.25;  // ... and MRS_SHARD_SPLIT_MAX_FRACTION: the boundary launch may cover at most this share of the blocks
   uint32_t  x_nbnd = 0;             // boundary blocks of this rank as of the last search
   double    x_dt = -1.0;            // dt of the previous call: the announcements of its last launches assumed it
   bool      rpm_over = false;       // some motor speed was set beyond its airframe's max_rpm: the displacement bound does not hold
@@ -732,6 +736,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
   if (const char* e = getenv("MRS_SHARD_SPLIT")) s->shard_split = atoi(e) != 0;
   if (const char* e = getenv("MRS_SHARD_SPLIT_MIN_BLOCKS")) s->split_min_blocks = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = getenv("MRS_SHARD_SPLIT_MAX_FRACTION")) s->split_max_fraction = atof(e);
   HIPCHK(hipMalloc(&s->dS, sizeof(double) * (size_t)F_COUNT * s->npad));
   HIPCHK(hipMalloc(&s->dF, sizeof(uint32_t) * (size_t)s->npad));
   HIPCHK(hipMalloc(&s->dDiag, sizeof(unsigned long long) * 4));
@@ -1574,7 +1579,28 @@ int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* 
   return MRS_OK;
 }
 
+extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int records, double width,
+                                                hipStream_t st);
+// The collective of the measurement stand-in: ONE kernel that takes `standin_delay_us` of stream time (a collective's latency) and
+// leaves the rank's own block in its own place and in the places of its two neighbours in the slab order — records (recognised by
+// their size) moved one slab width to either side, slot maps and export blocks as they are: the neighbours are periodic images of
+// this rank, so the export sets mirror each other as they do between real neighbours (positions of foreign partners are the
+// images' only at a search; between searches they read as far away — fine for a time measurement, meaningless as a simulation).
+int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
+  const bool records = bytes == sizeof(PosRecord) * (size_t)s->comm_n_max;
+  if (bytes % 16 != 0) {  // (the slot maps: 4 * (n_max + 2) bytes) plain copies, no latency worth modelling on a search tick
+    HIPCHK(hipMemsetAsync(recv, 0, bytes * (size_t)s->comm_world, s->stream));
+    for (int d = -1; d <= 1; d++)
+      if (s->comm_rank + d >= 0 && s->comm_rank + d < s->comm_world)
+        HIPCHK(hipMemcpyAsync((char*)recv + (size_t)(s->comm_rank + d) * bytes, send, bytes, hipMemcpyDeviceToDevice, s->stream));
+    return MRS_OK;
+  }
+  HIPCHK(mrs_launch_standin_gather(send, recv, bytes, s->comm_rank, s->comm_world, s->standin_delay_us, records ? 1 : 0, s->standin_width, s->stream));
+  return MRS_OK;
+}
+
 int comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
+  if (s->comm_standin) return standin_allgather(s, send, recv, bytes);
   if (s->rccl_comm) return rccl_check(g_rccl.AllGather(send, recv, bytes, /*ncclInt8*/ 0, s->rccl_comm, s->stream), "ncclAllGather");
   if (s->comm_group) return loopback_allgather(s->comm_group, s->comm_rank, send, recv, bytes, s->stream);
   if (s->comm_fn) {
@@ -1632,6 +1658,18 @@ int mrs_swarm_comm_init_custom(mrs_swarm_t* s, int32_t world, int32_t rank, int6
   HIPCHK(hipSetDevice(s->device));
   s->comm_fn   = fn;
   s->comm_user = user;
+  return comm_buffers(s, world, rank, n_total);
+}
+
+int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, double collective_latency_us, double slab_width) {
+  MRS_ENTER(s);
+  if (!s || !(collective_latency_us >= 0) || !(slab_width > 0)) return fail(MRS_ERR_ARG, "bad stand-in arguments");
+  int rc = comm_setup(s, world, rank, n_total);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  s->comm_standin     = true;
+  s->standin_delay_us = collective_latency_us;
+  s->standin_width    = slab_width;
   return comm_buffers(s, world, rank, n_total);
 }
 
@@ -1745,6 +1783,7 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   s->comm_fn    = nullptr;
   s->comm_user  = nullptr;
   s->comm_group = nullptr;
+  s->comm_standin = false;
   s->comm_world = 0;
   s->x_ok       = false;
   mrs_collide_invalidate_gathered(s->cwork);
@@ -1882,7 +1921,7 @@ int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval)
     CollDev  cd;
     SwarmDev v = s->view();
     HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
-    mrs_collide_export_part(&cd, MRS_PART_FULL, 0u, 0u, dt, s->rpm_over ? 0 : 1);
+    mrs_collide_export_part(&cd, MRS_PART_FULL, 0u, dt, s->rpm_over ? 0 : 1);
     s->region_launches++;
     const int variant = s->n_cascade > 0 ? 0 : 1;
     if (s->arith == MRS_ARITH_FAST)
@@ -1914,13 +1953,13 @@ int launch_split_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval,
     return s->arith == MRS_ARITH_FAST ? mrs_launch_step_coll_fast(v, c, dt, variant, grid, st) : mrs_launch_step_coll_literal(v, c, dt, variant, grid, st);
   };
   part = cd;
-  mrs_collide_export_part(&part, MRS_PART_BOUNDARY, s->x_nbnd, (s->tau + 1u - split_base) * grid_b, dt, bound_ok);
+  mrs_collide_export_part(&part, MRS_PART_BOUNDARY, s->x_nbnd, dt, bound_ok);
   HIPCHK(launch(part, (int)grid_b, s->stream));
   const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
   int rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
   if (rc) return rc;
   part = cd;
-  mrs_collide_export_part(&part, MRS_PART_INTERIOR, s->x_nbnd, 0u, dt, bound_ok);
+  mrs_collide_export_part(&part, MRS_PART_INTERIOR, s->x_nbnd, dt, bound_ok);
   HIPCHK(launch(part, 0, s->stream2));
   mrs_collide_fused_advance(s->cwork);
   s->tau++;
@@ -1954,7 +1993,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   s->x_dt = dt;
   const int nb = (s->n + 63) / 64;
   auto split_ok = [&]() {
-    return protocol_split && s->n > 0 && nb >= s->split_min_blocks && (long long)s->x_nbnd * 4 <= nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
+    return protocol_split && s->n > 0 && nb >= s->split_min_blocks && (double)s->x_nbnd <= s->split_max_fraction * nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
   };
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
@@ -2024,10 +2063,9 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
     }
     if (protocol_split) {
-      // What a rank's interior launches reported in the last ticks of the segment has not travelled yet (it rides with the boundary
-      // launch two ticks on): one more exchange of the export blocks, headers brought up to date, so that every rank ends the
-      // segment with the same words.  (All ranks do this, whichever form their own ticks took.)
-      HIPCHK(mrs_collide_export_header_refresh(s->cwork, s->stream));
+      // What a rank's interior launches reported in the last ticks of the segment sits in the header of its export block but has
+      // not travelled yet: one more exchange of the export blocks, so that every rank ends the segment with the same words.
+      // (All ranks do this, whichever form their own ticks took.)
       const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
       if ((rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes))) return rc;
     }

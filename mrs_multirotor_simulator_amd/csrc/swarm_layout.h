@@ -101,8 +101,11 @@ struct PosRecord {
 // latched (src/multirotor_simulator.cpp:321-358) and the step consumes it from registers.  Positions are double-buffered in
 // their own 32-B records so that the partners' values do not change under a running launch.
 struct Pos4 {
-  double x, y, z, w;  // w: header records carry flags here, position records 0
+  double x, y, z, w;  // position records: w = airframe type.  The HEADER record of an export block is read as 32-bit words instead:
+                      // word 0 = smallest stall index the rank knows of, word 1 = smallest warning index (0: none) — MRS_HDR_*
 };
+#define MRS_HDR_STALL 0
+#define MRS_HDR_WARN  1
 struct PartnerConst {
   double mass, arm_length, prop_radius, _pad;
 };
@@ -123,10 +126,8 @@ enum {
   CTL_STALL2 = 6,
   CTL_WARN2 = 7,
   CTL_ERROR = 8,     // bit 0: a bounded in-kernel wait ran out; bit 1: a UAV left its skin without the displacement bound announcing it
-  CTL_DONE_B = 9,    // tick index of the last boundary launch all of whose blocks have finished
-  CTL_TICKET_B = 10, // arrivals of boundary-launch blocks (cumulative since the hand-off words were last reset)
+  CTL_I_STARTED = 9, // tick index of the last interior launch that has started (so the interior launch before it is complete)
   CTL_NBND = 11,     // 64-UAV blocks of this rank that hold a boundary UAV (set by the search)
-  CTL_DONE_I0 = 12,  // tick index of the last interior launch whose first block has finished (so the launch before it is complete)
   CTL_WORDS = 16
 };
 // class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)
@@ -157,7 +158,7 @@ struct CollDev {
   const uint32_t*     blk_class;  // [blocks]
   const uint32_t*     blk_list;   // [n_bnd]
   uint32_t*           epoch;      // [blocks]
-  uint32_t            ticket_target, n_bnd;
+  uint32_t            n_bnd, _pad3;
   double              pred_hdt;   // horizon * dt (+inf: the bound cannot be given for this swarm — every tick announces)
   double              pred_lim;   // sqrt(lim2)
 };

@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
     "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component", "mrs_debug_pid_update", "mrs_swarm_set_state_pos", "mrs_swarm_set_pid", "mrs_swarm_clone",
-    "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay",
+    "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -257,6 +257,7 @@ def load_library():
         "mrs_swarm_debug_chaos": [vp, i32, C.c_uint64],
         "mrs_swarm_get_split_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_debug_stream_delay": [vp, C.c_double],
+        "mrs_swarm_comm_init_standin": [vp, i32, i32, C.c_int64, C.c_double, C.c_double],
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
@@ -473,6 +474,10 @@ class Swarm:
         d["parallelism"] = (f"{d['world']} equal-count shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, "
                             + ("RCCL" if d["rccl_ranks"] else "in-process / caller-supplied collective"))
         return d
+
+    def comm_init_standin(self, world, rank, n_total, collective_latency_us, slab_width):
+        """measurement stand-in: this rank alone, its neighbours are images of itself, every collective takes a fixed latency"""
+        _check(_lib.mrs_swarm_comm_init_standin(self._h, int(world), int(rank), int(n_total), float(collective_latency_us), float(slab_width)))
 
     def debug_chaos(self, max_sleep_us, seed=1):
         _check(_lib.mrs_swarm_debug_chaos(self._h, int(max_sleep_us), int(seed)))

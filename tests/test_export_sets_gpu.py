@@ -45,10 +45,12 @@ def run_ranks(fns):
 class VirtualShards:
     """`world` shards of one swarm given in PUBLIC index order; order[k] = public index at sorted position k"""
 
-    def __init__(self, M, world, order, po, pos, heading, st, mode, cmd, arith, exchange):
+    def __init__(self, M, world, order, po, pos, heading, st, mode, cmd, arith, exchange, rendezvous=False):
         from mrs_multirotor_simulator_amd.sharded import shard_range
         self.M, self.world, self.order, self.n_total = M, world, order, len(order)
         self.group = M.LoopbackGroup(world)
+        if rendezvous:
+            self.group.set_rendezvous(True)
         self.shards = []
         for r in range(world):
             lo, hi = shard_range(self.n_total, world, r)
