@@ -1172,9 +1172,12 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
 // the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
 // batch of ticks, whose last launch nobody has looked behind yet
 // progress_tau != 0: also stands in for the fused launch of a rank that holds no UAVs (it reports progress and the warning word)
-__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_send, volatile uint32_t* hostw, uint32_t progress_tau) {
+__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_send, const uint32_t* fctl, volatile uint32_t* hostw, uint32_t progress_tau) {
   uint32_t* own   = (uint32_t*)x_send;  // the rank's own header words (MRS_HDR_*): what it knows, what its next collective carries
   uint32_t  stall = own[MRS_HDR_STALL], warn = own[MRS_HDR_WARN];
+  // (a communicator of ONE rank: the launches keep their words where a single GPU keeps them)
+  if (fctl[CTL_STALL] != 0u && (stall == 0u || fctl[CTL_STALL] < stall)) stall = fctl[CTL_STALL];
+  if (fctl[CTL_WARN] != 0u && (warn == 0u || fctl[CTL_WARN] < warn)) warn = fctl[CTL_WARN];
   for (int q = 0; q < world; q++) {
     const uint32_t* hq = (const uint32_t*)(x_recv + (size_t)q * (size_t)block);
     const uint32_t  h = hq[MRS_HDR_STALL], wq = hq[MRS_HDR_WARN];
@@ -1389,7 +1392,7 @@ extern "C" hipError_t mrs_collide_latch_force(SwarmDev sw, CollideWork* w, int p
 extern "C" int mrs_collide_fused_pin(const CollideWork* w) { return w ? w->pcur : 0; }
 
 extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, unsigned progress_tau, hipStream_t st) {
-  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->x_send, w->hostw, progress_tau);
+  hipLaunchKernelGGL(k_fold_stall, dim3(1), dim3(1), 0, st, w->x_recv, w->x_world, (int)(w->x_cap + 1), w->x_send, w->fctl, w->hostw, progress_tau);
   return hipGetLastError();
 }
 
