@@ -1993,7 +1993,8 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   s->x_dt = dt;
   const int nb = (s->n + 63) / 64;
   auto split_ok = [&]() {
-    return protocol_split && s->n > 0 && nb >= s->split_min_blocks && (double)s->x_nbnd <= s->split_max_fraction * nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
+    // (a communicator of one rank has no boundary and announces nothing: its exact reports need the serial form)
+    return protocol_split && s->comm_world > 1 && s->n > 0 && nb >= s->split_min_blocks && (double)s->x_nbnd <= s->split_max_fraction * nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
   };
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
