@@ -50,6 +50,15 @@ constexpr double SKIN          = MRS_SKIN;    // neighbour lists: how far apart 
 constexpr double SQRT3_UP      = 1.7320508075688775;                      // >= sqrt(3)
 constexpr double INV_CELL_WIDE = 1.0 / (SQRT3_UP + SKIN + 0.0179491924);  // list rebuild: edge 2.25 m > sqrt(3) + SKIN = 2.2320508 (SKIN 0.5)
 constexpr double LIST_R2       = (SQRT3_UP + SKIN) * (SQRT3_UP + SKIN) * (1.0 + 1e-9) + 1e-5;  // > (sqrt(3) + SKIN)^2 (4.98206 at SKIN 0.5)
+// Sharded swarms keep their lists longer: a search there is two collectives, a host synchronisation and a dozen launches (~200 us
+// against 37 us on one GPU), so the wider skin — half as many searches, 1.3 instead of 0.7 listed partners per UAV at 64 m^3 — pays
+// (one GPU, SKIN swept: 0.5 m 22.9 us per tick, 1.0 m 23.6).  Mode 2 of the WIDE / LISTS template arguments below.
+#ifndef MRS_SKIN_SHARDED
+#define MRS_SKIN_SHARDED 1.0
+#endif
+constexpr double SKIN2          = MRS_SKIN_SHARDED;
+constexpr double INV_CELL_WIDE2 = 1.0 / (SQRT3_UP + SKIN2 + 0.0179491924);
+constexpr double LIST_R2_2      = (SQRT3_UP + SKIN2) * (SQRT3_UP + SKIN2) * (1.0 + 1e-9) + 1e-5;
 constexpr double POS_LIMIT     = MRS_POS_LIMIT;  // |coordinate| beyond this (or non-finite) never collides here
 // fused evaluation: a UAV beyond this fraction of the distance that invalidates the lists makes the host queue the next search in
 // stream order (no stall, no replay); the remaining 25 % (6 cm) are ten ticks at 6 m/s — more than the host runs ahead of the device
@@ -59,9 +68,9 @@ constexpr int    LIST_CAP      = 24;          // listed neighbours per UAV (0.7 
 
 struct Cell { int x, y, z; bool ok; };
 
-template <bool WIDE>
+template <int WIDE>  // 0: plain search cells, 1: list cells of one GPU, 2: list cells of a sharded swarm
 __device__ __forceinline__ Cell cell_of(double x, double y, double z) {
-  constexpr double ic = WIDE ? INV_CELL_WIDE : INV_CELL;
+  constexpr double ic = WIDE == 2 ? INV_CELL_WIDE2 : (WIDE ? INV_CELL_WIDE : INV_CELL);
   Cell c;
   c.ok = (fabs(x) < POS_LIMIT) && (fabs(y) < POS_LIMIT) && (fabs(z) < POS_LIMIT);  // false for NaN/inf
   c.x  = c.ok ? (int)floor(x * ic) : 0;
@@ -127,7 +136,7 @@ __device__ __forceinline__ void insert_uav(long long j, const Cell& c, uint32_t 
 }
 
 // ctl[0], ctl[1]: "some UAV has left its skin" flags of alternating ticks (written by the step kernel), see the header
-template <bool LISTS>
+template <int LISTS>
 __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask, uint2* head, uint2* next) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_total) return;
@@ -142,7 +151,7 @@ __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask,
 // reference path for one lane: repeated sweeps over the 27 bucket chains, each returning the smallest qualifying partner
 // index above the previous one (ascending-index accumulation without per-lane arrays).  Correct for any bucket
 // occupancy; used when the wave-cooperative path below overflows its LDS lists.
-template <bool WIDE>
+template <int WIDE>
 __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask,
                                   const uint2* head, const uint2* next, int crash, double rebounce, double& fx, double& fy, double& fz,
                                   bool& crashed) {
@@ -241,7 +250,7 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
 // single-GPU tick: pack and insert in one pass over the state (the records are still written: the query reads them).
 // With LISTS the pass only happens on a rebuild tick (the records then double as the reference positions of the skin test);
 // on every other tick this light kernel evaluates the neighbour lists and the query kernel that follows returns at once.
-template <bool LISTS>
+template <int LISTS>
 __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
                               int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
                               double rebounce, Pos4* pos_now, const uint32_t* stall_word) {
@@ -409,7 +418,7 @@ __global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRe
   if (j >= n_total) return;
   const PosRecord r = rec[j];
   if (!own_copy_only || (j >= my_offset && j < my_offset + sw.n)) rec_build[j] = r;  // (42 MB less to write per search at 8 x 125 k)
-  Cell            c = cell_of<true>(r.x, r.y, r.z);
+  Cell            c = cell_of<2>(r.x, r.y, r.z);
   // outside this rank's widened bounding box: nobody here can list it (a comparison with NaN bounds — no usable own record — is false)
   c.ok = c.ok && r.x >= bb[0] && r.y >= bb[1] && r.z >= bb[2] && r.x <= bb[3] && r.y <= bb[4] && r.z <= bb[5];
   insert_uav(j, c, mask, head, next);
@@ -469,7 +478,7 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
 // COMPACTED to the front (slot k < the number of entries read so far, so no unread entry is overwritten) — and the shrunken
 // list is swept again until every chain has ended.  Never more entries than the sweep started with: nothing can overflow, and
 // the later levels of the walk (a few percent of the heads) cost one short pass each instead of a pass over every head.
-template <bool LISTS>
+template <int LISTS>
 __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int lane, const PosRecord* rec, const uint2* next, long long wave_first,
                                              int crash) {
   // entries per lane and iteration.  Four looked right while the kernel waited on single round trips; since the record loads travel
@@ -527,7 +536,7 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
         const PosRecord m = L.me_s[ow];
         if (LISTS) {
           const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
-          if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < LIST_R2) {
+          if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < (LISTS == 2 ? LIST_R2_2 : LIST_R2)) {
             const uint32_t k = atomicAdd(&L.nl_n[ow], 1u);
             if (k < (uint32_t)LIST_CAP) L.nl_j[ow * LIST_CAP + k] = pe[u].x - 1u;
           }
@@ -546,7 +555,7 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
   }
 }
 
-template <bool LISTS>
+template <int LISTS>
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
                                               double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id,
@@ -923,7 +932,7 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   w->cur ^= 1;
   hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
                      w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur], guard_tau ? w->fctl + CTL_STALL : nullptr);
-  hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
+  hipLaunchKernelGGL(k_query<1>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, guard_tau ? w->fctl + CTL_STALL : nullptr, w->hostw, guard_tau);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
   w->lists_live = true;
@@ -971,7 +980,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
   const unsigned gN = (unsigned)((n_total + 255) / 256);
-  const double   lim2 = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  const double   lim2 = (0.5 * SKIN2) * (0.5 * SKIN2) * (1.0 - 1e-9);
   if (!w->g_bbox) CK(hipMalloc(&w->g_bbox, sizeof(double) * 6 * (BBOX_BLOCKS + 1)));  // the box, then the partial boxes
   if (force) {
     // (the search is decided: the comparison of all records with those of the last search would only cost time — 14 us at 1 M records;
@@ -982,10 +991,10 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   }
   // (also on list ticks: the device may decide on a search)
   hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, rec, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, force);
-  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN + 1e-6, w->g_bbox, w->ctl, w->fcur, force);
+  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, force);
   hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
                      w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->g_bbox, export_form ? 1 : 0);
-  hipLaunchKernelGGL(k_query<true>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
+  hipLaunchKernelGGL(k_query<2>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
                      rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, nullptr, nullptr, 0u);
   w->fcur ^= 1;
   w->g_lists_live  = true;
@@ -1340,7 +1349,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->send     = w->x_send;
   cd->exp_slot = w->exp_slot;
   cd->rebounce = rebounce;
-  cd->lim2     = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
+  cd->lim2     = (0.5 * SKIN2) * (0.5 * SKIN2) * (1.0 - 1e-9);
   cd->lim2_warn = cd->lim2 * (WARN_FRACTION * WARN_FRACTION);  // the warning travels in the collective's headers (swarm_host.hip: export_ticks)
   cd->tau      = tau;
   cd->n        = sw->n;
@@ -1352,7 +1361,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->blk_class = w->blk_class;
   cd->blk_list  = w->blk_list;
   cd->epoch     = w->epoch;
-  cd->pred_lim  = 0.5 * SKIN * (1.0 - 1e-9);
+  cd->pred_lim  = 0.5 * SKIN2 * (1.0 - 1e-9);
   cd->pred_hdt  = INFINITY;  // (the caller sets horizon * dt: mrs_collide_export_part)
   return hipSuccess;
 }
