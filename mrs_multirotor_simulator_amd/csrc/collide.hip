@@ -751,6 +751,7 @@ struct CollideWork {
   long long     exp_slot_cap = 0;
   // split sharded ticks: class of every 64-UAV block, list of the boundary blocks, epoch word per block (swarm_layout.h)
   uint32_t *    blk_class = nullptr, *blk_list = nullptr, *epoch = nullptr;
+  uint32_t*     host_heads = nullptr;  // pinned: heads of the slot maps + boundary-block count of the last search
   long long     blk_cap = 0;
   Pos4*         x_send = nullptr;     // [1 + x_cap]: header + exported positions of this rank
   Pos4*         x_recv = nullptr;     // [world][1 + x_cap]
@@ -764,7 +765,7 @@ static void free_work(CollideWork* w) {
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
   (void)hipFree(w->g_bbox);
   w->g_bbox = nullptr;
-  (void)hipFree(w->exp_slot); (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
+  (void)hipFree(w->exp_slot); (void)hipFree(w->x_send);  // (x_recv and x_const live in x_send's allocation)
   w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
   w->exp_slot_cap = w->x_cap = 0;
   (void)hipFree(w->blk_class); (void)hipFree(w->blk_list); (void)hipFree(w->epoch);
@@ -772,6 +773,8 @@ static void free_work(CollideWork* w) {
   w->blk_cap = 0;
   (void)hipFree(w->P[0]); (void)hipFree(w->P[1]); (void)hipFree(w->P[2]); (void)hipFree(w->fctl);
   if (w->hostw) (void)hipHostFree(w->hostw);
+  if (w->host_heads) (void)hipHostFree(w->host_heads);
+  w->host_heads = nullptr;
   w->P[0] = w->P[1] = w->P[2] = nullptr;
   w->p_cap = 0;
   w->fctl = w->hostw = nullptr;
@@ -1067,6 +1070,13 @@ __global__ void k_fill_positions(SwarmDev sw, Pos4* pos_now) {
   pos_now[i]      = pp;
 }
 
+__global__ void k_search_reset(uint32_t* fctl, uint32_t* map, long long n_map, uint32_t* blk_class, int n_blocks) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_map) map[i] = MRS_NO_SLOT;
+  if (i < n_blocks) blk_class[i] = 0u;
+  if (i < CTL_WORDS && i != CTL_ERROR) fctl[i] = 0u;
+}
+
 // map: [0] export count of this rank, [1] lanes over the list capacity so far, [2 + i] slot of own UAV i
 __global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot, uint32_t* map,
                               uint32_t* fctl, uint32_t* blk_class) {
@@ -1229,18 +1239,19 @@ extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work
   }
   if (cap > w->x_cap || world != w->x_world) {
     CK(hipStreamSynchronize(st));
-    (void)hipFree(w->x_send); (void)hipFree(w->x_recv); (void)hipFree(w->x_const);
+    (void)hipFree(w->x_send);  // (one allocation: send block, gathered blocks, partner constants — zeroed by one launch per search)
     const size_t block = (size_t)cap + 1;
-    CK(hipMalloc(&w->x_send, sizeof(Pos4) * block));
-    CK(hipMalloc(&w->x_recv, sizeof(Pos4) * block * (size_t)world));
-    CK(hipMalloc(&w->x_const, sizeof(PartnerConst) * block * (size_t)world));
+    char* base = nullptr;
+    CK(hipMalloc(&base, sizeof(Pos4) * block * (size_t)(1 + 2 * world)));
+    w->x_send  = (Pos4*)base;
+    w->x_recv  = w->x_send + block;
+    w->x_const = (PartnerConst*)(w->x_recv + block * (size_t)world);
     w->x_cap   = cap;
     w->x_world = world;
   }
   const size_t block = (size_t)w->x_cap + 1;
-  CK(hipMemsetAsync(w->x_send, 0, sizeof(Pos4) * block, st));
-  CK(hipMemsetAsync(w->x_recv, 0, sizeof(Pos4) * block * (size_t)world, st));
-  CK(hipMemsetAsync(w->x_const, 0, sizeof(PartnerConst) * block * (size_t)world, st));
+  static_assert(sizeof(Pos4) == sizeof(PartnerConst), "one stride for the three parts of the export allocation");
+  CK(hipMemsetAsync(w->x_send, 0, sizeof(Pos4) * block * (size_t)(1 + 2 * world), st));
   return hipSuccess;
 }
 
@@ -1299,6 +1310,26 @@ extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microsecond
   return hipGetLastError();
 }
 
+namespace {
+__global__ void k_heads_to_host(const uint32_t* maps, long long stride, int world, const uint32_t* fctl, volatile uint32_t* host) {
+  const int q = threadIdx.x;
+  if (q < world) {
+    __hip_atomic_store(&host[2 * q], maps[(size_t)q * (size_t)stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host[2 * q + 1], maps[(size_t)q * (size_t)stride + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (q == 0) __hip_atomic_store(&host[2 * world], fctl[CTL_NBND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+// what the host needs of a search — every rank's export count and overflow counter, this rank's boundary-block count — in pinned host
+// memory after ONE small launch (two device-to-host copies cost a search 30 us); valid after the stream has been synchronised
+extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st) {
+  if (!w || world > 64) return hipErrorInvalidValue;
+  if (!w->host_heads) CK(hipHostMalloc(&w->host_heads, sizeof(uint32_t) * 160, hipHostMallocMapped | hipHostMallocCoherent));
+  hipLaunchKernelGGL(k_heads_to_host, dim3(1), dim3(64), 0, st, maps, stride, world, w->fctl, w->host_heads);
+  *out = w->host_heads;
+  return hipGetLastError();
+}
+
 extern "C" long long mrs_collide_export_capacity(const CollideWork* w) { return w ? w->x_cap : 0; }
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w) { return w ? w->fctl : nullptr; }
 extern "C" void*     mrs_collide_export_send(const CollideWork* w) { return w ? (void*)w->x_send : nullptr; }
@@ -1306,13 +1337,12 @@ extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? 
 
 // after a search over gathered records: mark the export set, write this rank's slot map (2 + n_max words) for the all-gather
 extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st) {
-  CK(hipMemsetAsync(w->fctl, 0, sizeof(uint32_t) * CTL_ERROR, st));  // (the error word stays: it is reported at the end of the call)
-  CK(hipMemsetAsync(w->fctl + CTL_ERROR + 1, 0, sizeof(uint32_t) * (CTL_WORDS - CTL_ERROR - 1), st));
-  CK(hipMemsetAsync(map_send, 0xFF, sizeof(uint32_t) * (size_t)(n_max + 2), st));  // padding UAVs: no slot
+  // control words (the error word stays: it is reported at the end of the call), slot map (padding UAVs: no slot), block classes: ONE launch
+  hipLaunchKernelGGL(k_search_reset, dim3((unsigned)((n_max + 2 + 255) / 256)), dim3(256), 0, st, w->fctl, map_send, n_max + 2, w->blk_class,
+                     (sw.n + 63) / 64);
   w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
   if (sw.n > 0) {
     const int n_blocks = (sw.n + 63) / 64;
-    CK(hipMemsetAsync(w->blk_class, 0, sizeof(uint32_t) * (size_t)n_blocks, st));
     hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl,
                        w->blk_class);
     hipLaunchKernelGGL(k_class_list, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, w->blk_class, w->blk_list, w->fctl);

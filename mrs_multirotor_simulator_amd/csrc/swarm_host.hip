@@ -68,6 +68,7 @@ extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double 
 extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int bound_ok);
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
+extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
@@ -1887,13 +1888,10 @@ int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
   HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, rank, s->x_map_send, s->stream));
   if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
   // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
-  std::vector<unsigned> heads((size_t)world * 2);
-  HIPCHK(hipMemcpy2DAsync(heads.data(), 2 * sizeof(unsigned), s->x_map_recv, sizeof(uint32_t) * (size_t)stride, 2 * sizeof(unsigned), (size_t)world,
-                          hipMemcpyDeviceToHost, s->stream));
-  unsigned nbnd = 0;
-  if (s->n > 0) HIPCHK(hipMemcpyAsync(&nbnd, mrs_collide_ctl_words(s->cwork) + CTL_NBND, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+  const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch)
+  HIPCHK(mrs_collide_heads_to_host(s->cwork, s->x_map_recv, stride, world, &heads, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->x_nbnd = nbnd;
+  s->x_nbnd = s->n > 0 ? heads[2 * world] : 0u;
   long long need = 0;
   for (int q = 0; q < world; q++) {
     if ((long long)heads[(size_t)q * 2] > need) need = heads[(size_t)q * 2];
