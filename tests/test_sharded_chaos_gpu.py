@@ -58,3 +58,36 @@ def test_sharded_ticks_under_host_skew(mrs, oracle, monkeypatch, world, rendezvo
     assert sum(t for t, _ in split) > 40 * world, split  # the split form really ran (4 ticks after every search and call are serial)
     print(f"chaos, world {world}, {'rendezvous' if rendezvous else 'barrier'} loopback: searches {[ci['searches'] for ci in info]}, "
           f"ticks replayed {[ci['noop_ticks'] for ci in info]}, split ticks / boundary blocks {split}")
+
+
+def test_split_ticks_when_the_displacement_bound_cannot_be_given(mrs, oracle, monkeypatch):
+    """A motor speed beyond the airframe's max_rpm (set through set_state) voids the thrust cap behind the announcements: that rank
+    announces on every tick (searches every few ticks) — slower, and still exactly the oracle's results."""
+    M = mrs
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MIN_BLOCKS", "1")
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MAX_FRACTION", "0.95")
+    world, n_total = 2, 3000
+    rng = np.random.default_rng(77)
+    pos, st, cmd = moving_swarm(rng, n_total, speed=3.0)
+    st["motor_rpm"][5, :4] = 9500.0  # x500: max_rpm 7800 (airframes.py) — the low-pass brings it back, the bound cannot know when
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    assert st["motor_rpm"][5, 0] > po.max_rpm
+    o = oracle.OracleSwarm(n_total)
+    o.construct(0, n_total, po, pos, np.zeros(n_total))
+    o.set_state(0, n_total, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, n_total, oracle.ACTUATOR_CMD, cmd)
+    order = M.slab_partition(pos, world)
+    vs = VirtualShards(M, world, order, helpers.to_product_params(M, po), pos, np.zeros(n_total), st, M.ACTUATOR_CMD, cmd, M.ARITH_LITERAL,
+                       M.EXCHANGE_EXPORT_SETS)
+    vs.tick_n(80, True, False, 100.0)
+    for _ in range(80):
+        o.step(DT)
+        o.handle_collisions(True, False, 100.0)
+    a, so = vs.gather(), o.get_state()
+    helpers.assert_close(a["f"], o.get_external_force(), 1e-11, "forces")
+    for k in ("x", "v", "R", "omega", "motor_rpm"):
+        helpers.assert_close(a[k], so[k], RTOL_LITERAL, k)
+    info = vs.info()
+    vs.close()
+    where = int(np.flatnonzero(order == 5)[0]) * world // n_total
+    assert info[where]["searches"] >= 10, info  # the rank that holds UAV 5 announces every tick: a search about every 5 ticks
