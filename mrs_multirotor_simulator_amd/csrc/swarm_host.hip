@@ -296,6 +296,13 @@ struct mrs_swarm {
   // a run of steps without collisions in between is issued as two half-swarm launches per step on two streams: the halves are
   // independent, so the drain of one launch overlaps the ramp of the other (tools/two_streams.py: +11 % at 100 k, +19 % at 200 k)
   hipStream_t stream2 = nullptr;
+  // Split sharded ticks with reserved compute units (MRS_SPLIT_CU_RESERVE = R > 0; tools/cu_mask_probe.hip): the boundary launch and the
+  // collective run on `stream_b`, whose queue may use R CUs only (mask bits 0..R-1: bit i is CU i / 8 of XCD i % 8), the interior
+  // launch on `stream_i`, whose queue uses all the others — the lone waves of the boundary chain no longer share SIMDs with the
+  // streaming interior waves.  `cstream`: where collectives and boundary launches go right now (`stream` outside split segments).
+  hipStream_t stream_b = nullptr, stream_i = nullptr, cstream = nullptr;
+  hipEvent_t  ev_join_b = nullptr;
+  int         cu_reserve = 0;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t  ev_end2 = nullptr;   // profiling: end of the second stream's part of a split run (recorded before the join)
   bool        prof_split = false;  // the end events of the running profile region have been recorded by the split run itself
@@ -731,6 +738,19 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   }
   HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_join_b, hipEventDisableTiming));
+  s->cstream = s->stream;
+  if (const char* e = getenv("MRS_SPLIT_CU_RESERVE")) s->cu_reserve = atoi(e);
+  if (s->cu_reserve > 0) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    if (s->cu_reserve >= ncu / 2) return fail(MRS_ERR_ARG, "MRS_SPLIT_CU_RESERVE: at most half of the device's compute units");
+    std::vector<uint32_t> mb((size_t)words, 0u), mi((size_t)words, 0u);
+    for (int b = 0; b < ncu; b++) (b < s->cu_reserve ? mb : mi)[(size_t)(b / 32)] |= 1u << (b % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&s->stream_b, (uint32_t)words, mb.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&s->stream_i, (uint32_t)words, mi.data()));
+  }
   HIPCHK(hipEventCreate(&s->ev_end2));
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
@@ -760,6 +780,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->stream2) (void)hipStreamSynchronize(s->stream2);
+  if (s->stream_b) (void)hipStreamSynchronize(s->stream_b);
+  if (s->stream_i) (void)hipStreamSynchronize(s->stream_i);
   for (auto e : s->ev) (void)hipEventDestroy(e);
   mrs_collide_free(s->cwork);
   if (s->dRec) (void)hipFree(s->dRec);
@@ -782,6 +804,9 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->ev_end2) (void)hipEventDestroy(s->ev_end2);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
+  if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
+  if (s->stream_i) (void)hipStreamDestroy(s->stream_i);
+  if (s->ev_join_b) (void)hipEventDestroy(s->ev_join_b);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return MRS_OK;
@@ -1590,22 +1615,22 @@ extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, si
 int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
   const bool records = bytes == sizeof(PosRecord) * (size_t)s->comm_n_max;
   if (bytes % 16 != 0) {  // (the slot maps: 4 * (n_max + 2) bytes) plain copies, no latency worth modelling on a search tick
-    HIPCHK(hipMemsetAsync(recv, 0, bytes * (size_t)s->comm_world, s->stream));
+    HIPCHK(hipMemsetAsync(recv, 0, bytes * (size_t)s->comm_world, s->cstream));
     for (int d = -1; d <= 1; d++)
       if (s->comm_rank + d >= 0 && s->comm_rank + d < s->comm_world)
-        HIPCHK(hipMemcpyAsync((char*)recv + (size_t)(s->comm_rank + d) * bytes, send, bytes, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync((char*)recv + (size_t)(s->comm_rank + d) * bytes, send, bytes, hipMemcpyDeviceToDevice, s->cstream));
     return MRS_OK;
   }
-  HIPCHK(mrs_launch_standin_gather(send, recv, bytes, s->comm_rank, s->comm_world, s->standin_delay_us, records ? 1 : 0, s->standin_width, s->stream));
+  HIPCHK(mrs_launch_standin_gather(send, recv, bytes, s->comm_rank, s->comm_world, s->standin_delay_us, records ? 1 : 0, s->standin_width, s->cstream));
   return MRS_OK;
 }
 
 int comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
   if (s->comm_standin) return standin_allgather(s, send, recv, bytes);
-  if (s->rccl_comm) return rccl_check(g_rccl.AllGather(send, recv, bytes, /*ncclInt8*/ 0, s->rccl_comm, s->stream), "ncclAllGather");
-  if (s->comm_group) return loopback_allgather(s->comm_group, s->comm_rank, send, recv, bytes, s->stream);
+  if (s->rccl_comm) return rccl_check(g_rccl.AllGather(send, recv, bytes, /*ncclInt8*/ 0, s->rccl_comm, s->cstream), "ncclAllGather");
+  if (s->comm_group) return loopback_allgather(s->comm_group, s->comm_rank, send, recv, bytes, s->cstream);
   if (s->comm_fn) {
-    const int rc = s->comm_fn(s->comm_user, send, recv, (uint64_t)bytes, (void*)s->stream);
+    const int rc = s->comm_fn(s->comm_user, send, recv, (uint64_t)bytes, (void*)s->cstream);
     return rc == 0 ? MRS_OK : fail(MRS_ERR_HIP, "the caller's all-gather failed with code " + std::to_string(rc));
   }
   return fail(MRS_ERR_ARG, "no communicator");
@@ -1952,13 +1977,13 @@ int launch_split_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval,
   };
   part = cd;
   mrs_collide_export_part(&part, MRS_PART_BOUNDARY, s->x_nbnd, dt, bound_ok);
-  HIPCHK(launch(part, (int)grid_b, s->stream));
+  HIPCHK(launch(part, (int)grid_b, s->cstream));
   const size_t bytes = sizeof(Pos4) * (size_t)(mrs_collide_export_capacity(s->cwork) + 1);
   int rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes);
   if (rc) return rc;
   part = cd;
   mrs_collide_export_part(&part, MRS_PART_INTERIOR, s->x_nbnd, dt, bound_ok);
-  HIPCHK(launch(part, 0, s->stream2));
+  HIPCHK(launch(part, 0, s->stream_i ? s->stream_i : s->stream2));
   mrs_collide_fused_advance(s->cwork);
   s->tau++;
   s->x_split_ticks++;
@@ -1987,6 +2012,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   const bool protocol_split = s->shard_split;  // (the same on every rank: it sets how long a report takes to reach everybody)
   const unsigned lead = (unsigned)(s->fused_lead > 0 ? s->fused_lead : 1), search_ahead = lead + (protocol_split ? 6u : 3u);
   int serial_left = (int)MRS_PRED_HORIZON;
+  s->cstream = s->stream;  // (a call that failed inside a split segment may have left it elsewhere)
   if (dt != s->x_dt) s->x_ok = false;  // the announcements of the last call's final launches assumed its dt: start from a search
   s->x_dt = dt;
   const int nb = (s->n + 63) / 64;
@@ -2045,7 +2071,11 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
         HIPCHK(mrs_collide_export_fold_stall(s->cwork, 0u, s->stream));
         HIPCHK(mrs_collide_handoff_init(s->cwork, s->n, s->tau, s->stream));
         HIPCHK(hipEventRecord(s->ev_fork, s->stream));
-        HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(s->stream_i ? s->stream_i : s->stream2, s->ev_fork, 0));
+        if (s->stream_b) {
+          HIPCHK(hipStreamWaitEvent(s->stream_b, s->ev_fork, 0));
+          s->cstream = s->stream_b;
+        }
         in_split   = true;
         split_base = s->tau;
       }
@@ -2058,8 +2088,13 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       pending = true;
     }
     if (in_split) {  // back to one stream: everything that follows (fold, search, the caller's work) comes behind the interior launches too
-      HIPCHK(hipEventRecord(s->ev_join, s->stream2));
+      HIPCHK(hipEventRecord(s->ev_join, s->stream_i ? s->stream_i : s->stream2));
       HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+      if (s->stream_b) {
+        HIPCHK(hipEventRecord(s->ev_join_b, s->stream_b));
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_join_b, 0));
+        s->cstream = s->stream;
+      }
     }
     if (protocol_split) {
       // What a rank's interior launches reported in the last ticks of the segment sits in the header of its export block but has
