@@ -135,6 +135,9 @@ def parse():
     ap.add_argument("--config5-timeout", type=float, default=240.0, help="seconds after which the config-5 leg is given up (the headline line is printed regardless)")
     ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
     ap.add_argument("--config5-shards", choices=["slabs", "index"], default="slabs", help="x-sorted slabs (boundary sets stay small) or index ranges")
+    ap.add_argument("--config5-transport", choices=["rccl", "peer"], default="rccl",
+                    help="collective backend of the config-5 leg: RCCL all-gather, or the library's peer-window exchange (direct writes into the "
+                         "peers' device memory over xGMI, IPC handles carried by torch.distributed; never run across devices yet: opt-in)")
     ap.add_argument("--config5-exchange", choices=["export", "full"], default="export",
                     help="export: boundary UAVs only between two searches; full: all 48-B records on every tick")
     return ap.parse_args()
@@ -447,12 +450,18 @@ def config5_leg(args, R):
     sw.set_state(0, n, st["x"][own], st["v"][own], st["R"][own], st["omega"][own], st["motor_rpm"][own])
     sw.set_input(0, n, M.POSITION_CMD, cmd[own])
     del st, cmd
-    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-    if R.rank == 0:
-        uid = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).cuda()
-    if R.use_dist:
-        dist.broadcast(uid, 0)
-    sw.comm_init(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()), n_total)
+    if args.config5_transport == "peer" and R.use_dist:
+        _, handle = sw.peer_window_create(R.world, R.rank, n_total)
+        handles = [None] * R.world
+        dist.all_gather_object(handles, handle)
+        sw.comm_init_peer(handles=handles)
+    else:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if R.rank == 0:
+            uid = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).cuda()
+        if R.use_dist:
+            dist.broadcast(uid, 0)
+        sw.comm_init(R.world, R.rank, bytes(uid.cpu().numpy().tobytes()), n_total)
     sw.set_exchange(M.EXCHANGE_FULL_GATHER if args.config5_exchange == "full" else M.EXCHANGE_EXPORT_SETS)
 
     def run(k):
@@ -473,11 +482,14 @@ def config5_leg(args, R):
            "value": n_total * steps / el, "unit": "UAV-steps/s", "ms_per_tick": el / steps * 1e3, "n_total": n_total, "n_gpus": R.world,
            "steps": steps, "warmup": warmup, "regions": len(times), "scaling": "strong",
            "parallelism": info["parallelism"], "rccl_ranks": info["rccl_ranks"],
+           "transport": args.config5_transport if R.use_dist else "rccl",
            "shards": args.config5_shards,
            "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collective_bytes_per_rank_per_search_tick": info["bytes_per_rebuild"],
            "export_set_of_rank0": info["export_count"], "export_capacity": info["export_capacity"], "uavs_per_rank": n,
            "sharded_ticks": info["ticks"], "search_ticks": info["searches"], "replayed_noop_ticks": info["noop_ticks"],
            "collision_ticks": int(ticks), "neighbour_searches": int(searches)}
+    if R.use_dist:
+        dist.barrier()  # (peer windows: nobody unmaps a window a peer may still write into)
     sw.comm_destroy()
     del sw
     return out if R.rank == 0 else None

@@ -265,6 +265,22 @@ int mrs_debug_stream_delay(void* stream, double microseconds);
  * `slab_width` metres away — boundary sets, launches and buffer sizes of the real run, none of its physics across the slab faces.
  * Not a simulation backend. */
 int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, double collective_latency_us, double slab_width);
+/* Peer-window exchange — the collectives of the sharded tick as direct writes into the peers' device memory over xGMI, no
+ * collective library and no host in the tick (one small kernel per collective on the swarm's stream: push into every peer's
+ * window, signal, wait for every peer's signal, pull — csrc/collide.hip k_peer_allgather).  xGMI is point to point: a rank's block
+ * reaches every peer in ONE hop, where a ring all-gather pays 2 (world - 1) hops behind its own kernel launch.
+ *   mrs_swarm_peer_window_create : allocates this rank's window (4096 + 2 * world * slot bytes, slot = the largest shard's full
+ *       gather) and returns its address (`window`, for peers in the same process) and / or its 64-byte IPC handle (`ipc_handle64`,
+ *       for peers in other processes: hipIpcMemHandle_t) — either may be NULL;
+ *   mrs_swarm_comm_init_peer     : binds the communicator once the caller has carried the addresses / handles to every rank by any
+ *       host channel: `windows[q]` (if given and not NULL) is rank q's window as THIS process addresses it (same process, or a
+ *       device with peer access enabled), otherwise `ipc_handles + 64 q` is opened.  The entries of the own rank are ignored.
+ * Afterwards mrs_swarm_tick_sharded_n / mrs_swarm_comm_destroy as with any other backend (destroy only after every rank's last
+ * tick call has returned: peers write into the window until then).  A rank that waits 10 s for a peer's block gives up and the
+ * call returns MRS_ERR_HIP.  Ranks in one process on ONE device (tests) need a hardware queue per rank: GPU_MAX_HW_QUEUES >= 2 * world
+ * in the environment before the HIP runtime starts — kernels of different ranks wait for each other on the device. */
+int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, void** window, uint8_t* ipc_handle64);
+int mrs_swarm_comm_init_peer(mrs_swarm_t* s, void* const* windows, const uint8_t* ipc_handles);
 int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange);
 int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled, int32_t crash, double rebounce);
 int mrs_swarm_comm_destroy(mrs_swarm_t* s);

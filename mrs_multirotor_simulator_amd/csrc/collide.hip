@@ -1305,6 +1305,91 @@ extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, si
                      (long long)(latency_us * 100.0));
   return hipGetLastError();
 }
+// ---- peer-window all-gather: the exchange of a sharded swarm WITHOUT a collective library in the tick ----
+// Every rank owns a WINDOW in its own device memory (fine-grained, mapped into every peer: hipIpcOpenMemHandle across processes,
+// plain pointers inside one): [world flag lines of 64 B | pad to 4096 | 2 parities x world slots of slot_bytes].  One kernel per
+// rank and collective, no host in between.  A group of `bpp` blocks serves ONE peer q (the group of the own rank copies the own
+// block into the receive buffer and is done):
+//   1. push   — the group's shares of the rank's block go straight into slot [seq & 1][rank] of q's window (system-scope stores:
+//               one hop over xGMI);
+//   2. signal — every block fences its stores (system scope); the last block of the group (a ticket when bpp > 1) writes seq into
+//               flag[rank] of q's window;
+//   3. wait   — one lane polls flag[q] of the OWN window until q has signalled seq (bounded: 10 s, then the error word is set and
+//               the kernel ends — the call reports it), acquire;
+//   4. pull   — q's slot is copied from the own window into the receive buffer (system-scope loads: another device wrote the lines).
+// On exit the receive buffer holds what an all-gather would have put there, so the caller's kernels do not know the difference;
+// no block waits for another block of its own launch except through the ticket, which needs no residency (it is taken after the work).
+// Two parities suffice: a peer can only be one collective ahead (it cannot finish seq+1 without this rank's flag for seq+1, which
+// is written by this rank's kernel seq+1, i.e. after its kernel seq has ended), so what it writes while this rank still pulls seq
+// goes to the other parity.
+// Cost: one one-way latency + the copy, where a ring all-gather pays 2 (world - 1) hops behind a kernel launch of its own.
+namespace {
+typedef __attribute__((address_space(1))) unsigned long long peer_u64;
+typedef __attribute__((address_space(1))) unsigned           peer_u32;
+template <class U> struct PeerWord;
+template <> struct PeerWord<unsigned long long> { typedef peer_u64 G; };
+template <> struct PeerWord<unsigned>           { typedef peer_u32 G; };
+#define MRS_PEER_THREADS 512
+
+template <class U>
+__global__ __launch_bounds__(MRS_PEER_THREADS) void k_peer_allgather(MrsPeerWindows pw, const U* __restrict__ send, U* __restrict__ recv, long long units,
+                                                                     int rank, int bpp, unsigned seq, unsigned long long slot_bytes,
+                                                                     unsigned* tickets, unsigned ticket_target, unsigned* err_host, int world) {
+  typedef typename PeerWord<U>::G G;
+  const int       q = (int)blockIdx.x / bpp, j = (int)blockIdx.x - q * bpp;
+  const long long share = (units + bpp - 1) / bpp, lo = (long long)j * share, hi = lo + share < units ? lo + share : units;
+  if (q == rank) {
+    for (long long u = lo + threadIdx.x; u < hi; u += MRS_PEER_THREADS) recv[(long long)rank * units + u] = send[u];
+    return;
+  }
+  // 1. push
+  G* there = (G*)((char*)pw.win[q] + 4096ull + ((unsigned long long)(seq & 1u) * (unsigned)world + (unsigned)rank) * slot_bytes);
+  for (long long u = lo + threadIdx.x; u < hi; u += MRS_PEER_THREADS) __hip_atomic_store(there + u, send[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // 2. signal
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (bpp > 1) last = __hip_atomic_fetch_add((peer_u32*)(tickets + q), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == ticket_target;
+    if (last) __hip_atomic_store((peer_u32*)((char*)pw.win[q] + 64 * rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3. wait
+    const peer_u32* flag = (const peer_u32*)((const char*)pw.win[rank] + 64 * q);
+    const long long t0   = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (wall_clock64() - t0 > MRS_WAIT_TICKS) {
+        __hip_atomic_store((peer_u32*)err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (pinned host word: a plain store, no PCIe atomic)
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  // 4. pull
+  const G* here = (const G*)((const char*)pw.win[rank] + 4096ull + ((unsigned long long)(seq & 1u) * (unsigned)world + (unsigned)q) * slot_bytes);
+  for (long long u = lo + threadIdx.x; u < hi; u += MRS_PEER_THREADS)
+    recv[(long long)q * units + u] = __hip_atomic_load(here + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+// `ticket_total`: tickets every peer's word has seen from all earlier launches of this rank (the caller adds the returned `bpp`)
+extern "C" hipError_t mrs_launch_peer_allgather(const MrsPeerWindows* pw, const void* send, void* recv, size_t bytes, int rank, int world, unsigned seq,
+                                                size_t slot_bytes, unsigned* tickets, unsigned ticket_total, unsigned* err_host, unsigned* bpp_out,
+                                                hipStream_t st) {
+  if (bytes == 0 || bytes % 4 != 0 || bytes > slot_bytes || world < 1 || world > MRS_MAX_PEERS) return hipErrorInvalidValue;
+  const bool      wide  = bytes % 8 == 0;
+  const long long units = (long long)(bytes / (wide ? 8 : 4));
+  long long       bpp   = ((long long)bytes + 131071) / 131072;  // one block per peer up to 128 KiB (the per-tick export blocks), then one per 128 KiB
+  if (bpp > 16) bpp = 16;
+  *bpp_out = bpp > 1 ? (unsigned)bpp : 0u;  // (a group of one block takes no ticket)
+  const dim3 grid((unsigned)(bpp * world)), block(MRS_PEER_THREADS);
+  if (wide)
+    hipLaunchKernelGGL(k_peer_allgather<unsigned long long>, grid, block, 0, st, *pw, (const unsigned long long*)send, (unsigned long long*)recv, units, rank,
+                       (int)bpp, seq, (unsigned long long)slot_bytes, tickets, ticket_total + (unsigned)bpp, err_host, world);
+  else
+    hipLaunchKernelGGL(k_peer_allgather<unsigned>, grid, block, 0, st, *pw, (const unsigned*)send, (unsigned*)recv, units, rank, (int)bpp, seq,
+                       (unsigned long long)slot_bytes, tickets, ticket_total + (unsigned)bpp, err_host, world);
+  return hipGetLastError();
+}
 extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microseconds) {
   hipLaunchKernelGGL(k_stream_delay, dim3(1), dim3(64), 0, st, (long long)(microseconds * 100.0));
   return hipGetLastError();

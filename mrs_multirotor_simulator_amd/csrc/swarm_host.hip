@@ -325,6 +325,18 @@ struct mrs_swarm {
   // are images of itself one slab width away, and every collective costs a fixed latency
   bool   comm_standin = false;
   double standin_delay_us = 0.0, standin_width = 0.0;
+  // peer-window exchange (mrs_swarm_peer_window_create / mrs_swarm_comm_init_peer; collide.hip k_peer_allgather): ranks write their
+  // blocks straight into each other's device memory, one kernel per collective on the swarm's stream, no collective library
+  bool               comm_peer = false;
+  void*              peer_window = nullptr;       // this rank's window (fine-grained device memory)
+  size_t             peer_slot_bytes = 0, peer_window_bytes = 0;
+  int                peer_world = 0, peer_rank = 0;
+  int64_t            peer_n_total = 0;
+  MrsPeerWindows     peer_windows{};              // every rank's window as this process addresses it
+  std::vector<void*> peer_opened;                 // the ones mapped here through an IPC handle (closed by comm_destroy)
+  unsigned           peer_seq = 0, peer_tickets = 0;
+  unsigned*          peer_ticket = nullptr;       // device words, one per peer: blocks of all exchange kernels so far that have pushed their share for it
+  unsigned*          peer_err = nullptr;          // pinned host word: an exchange kernel waited in vain for a peer
   // export-set exchange: between two searches only boundary UAVs travel
   int       exchange = MRS_EXCHANGE_EXPORT_SETS;
   bool      x_ok = false;           // export lists are live: the next tick can be a fused launch + export-set all-gather
@@ -775,6 +787,9 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   return MRS_OK;
 }
 
+namespace {
+void peer_release(mrs_swarm* s);
+}
 int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (!s) return MRS_OK;
   (void)hipSetDevice(s->device);
@@ -796,6 +811,7 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->dF) (void)hipFree(s->dF);
   if (s->dS) (void)hipFree(s->dS);
   if (s->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->rccl_comm);
+  peer_release(s);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
   if (s->x_map_send) (void)hipFree(s->x_map_send);
@@ -1605,6 +1621,9 @@ int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* 
   return MRS_OK;
 }
 
+extern "C" hipError_t mrs_launch_peer_allgather(const MrsPeerWindows* pw, const void* send, void* recv, size_t bytes, int rank, int world, unsigned seq,
+                                                size_t slot_bytes, unsigned* tickets, unsigned ticket_total, unsigned* err_host, unsigned* bpp_out,
+                                                hipStream_t st);
 extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int records, double width,
                                                 hipStream_t st);
 // The collective of the measurement stand-in: ONE kernel that takes `standin_delay_us` of stream time (a collective's latency) and
@@ -1625,7 +1644,18 @@ int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) 
   return MRS_OK;
 }
 
+// the peer-window exchange: every rank issues the same collectives in the same order, so the sequence number is the same everywhere
+int peer_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
+  if (bytes > s->peer_slot_bytes) return fail(MRS_ERR_ARG, "peer-window exchange: a block of " + std::to_string(bytes) + " bytes does not fit the window's slots (" + std::to_string(s->peer_slot_bytes) + ")");
+  unsigned taken = 0;
+  HIPCHK(mrs_launch_peer_allgather(&s->peer_windows, send, recv, bytes, s->comm_rank, s->comm_world, ++s->peer_seq, s->peer_slot_bytes, s->peer_ticket,
+                                   s->peer_tickets, s->peer_err, &taken, s->cstream));
+  s->peer_tickets += taken;
+  return MRS_OK;
+}
+
 int comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
+  if (s->comm_peer) return peer_allgather(s, send, recv, bytes);
   if (s->comm_standin) return standin_allgather(s, send, recv, bytes);
   if (s->rccl_comm) return rccl_check(g_rccl.AllGather(send, recv, bytes, /*ncclInt8*/ 0, s->rccl_comm, s->cstream), "ncclAllGather");
   if (s->comm_group) return loopback_allgather(s->comm_group, s->comm_rank, send, recv, bytes, s->cstream);
@@ -1685,6 +1715,94 @@ int mrs_swarm_comm_init_custom(mrs_swarm_t* s, int32_t world, int32_t rank, int6
   s->comm_fn   = fn;
   s->comm_user = user;
   return comm_buffers(s, world, rank, n_total);
+}
+
+namespace {
+void peer_release(mrs_swarm* s) {
+  for (void* p : s->peer_opened) (void)hipIpcCloseMemHandle(p);
+  s->peer_opened.clear();
+  if (s->peer_window) (void)hipFree(s->peer_window);
+  if (s->peer_ticket) (void)hipFree(s->peer_ticket);
+  if (s->peer_err) (void)hipHostFree(s->peer_err);
+  s->peer_window = nullptr;
+  s->peer_ticket = s->peer_err = nullptr;
+  s->peer_world  = 0;
+  s->comm_peer   = false;
+}
+}  // namespace
+
+int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, void** window, uint8_t* ipc_handle64) {
+  MRS_ENTER(s);
+  if (!s || world > MRS_MAX_PEERS) return fail(MRS_ERR_ARG, "bad peer-window arguments (at most 64 ranks)");
+  int rc = comm_setup(s, world, rank, n_total);
+  if (rc) return rc;
+  if (s->peer_window) return fail(MRS_ERR_ARG, "this swarm already has a peer window");
+  HIPCHK(hipSetDevice(s->device));
+  // the largest block any collective of the sharded tick sends: the full gather of a search (one record per UAV of the largest shard)
+  const int64_t n_max = (n_total + world - 1) / world > 0 ? (n_total + world - 1) / world : 1;
+  size_t slot = sizeof(PosRecord) * (size_t)n_max;
+  if (slot < sizeof(uint32_t) * (size_t)(n_max + 2)) slot = sizeof(uint32_t) * (size_t)(n_max + 2);
+  slot = (slot + 255) / 256 * 256;
+  s->peer_slot_bytes   = slot;
+  s->peer_window_bytes = 4096 + 2 * (size_t)world * slot;
+  // fine-grained: written by other devices while kernels of this one read it (MRS_PEER_WINDOW_COARSE=1: ordinary device memory,
+  // for runtimes that cannot export fine-grained allocations — every access of the exchange kernel is system-scope either way)
+  const char* coarse = getenv("MRS_PEER_WINDOW_COARSE");
+  if (coarse && atoi(coarse) != 0)
+    HIPCHK(hipMalloc(&s->peer_window, s->peer_window_bytes));
+  else
+    HIPCHK(hipExtMallocWithFlags(&s->peer_window, s->peer_window_bytes, hipDeviceMallocFinegrained));
+  HIPCHK(hipMalloc((void**)&s->peer_ticket, sizeof(unsigned) * MRS_MAX_PEERS));
+  HIPCHK(hipHostMalloc((void**)&s->peer_err, 64, hipHostMallocMapped));
+  *s->peer_err = 0u;
+  HIPCHK(hipMemsetAsync(s->peer_window, 0, 4096, s->stream));  // flags: no collective has happened
+  HIPCHK(hipMemsetAsync(s->peer_ticket, 0, sizeof(unsigned) * MRS_MAX_PEERS, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));  // ... before any peer can learn the address
+  if (ipc_handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries IPC handles as 64 bytes");
+    hipIpcMemHandle_t h;
+    const hipError_t  e = hipIpcGetMemHandle(&h, s->peer_window);
+    if (e != hipSuccess) {
+      peer_release(s);
+      return fail(MRS_ERR_HIP, std::string("peer window: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    }
+    memcpy(ipc_handle64, &h, 64);
+  }
+  if (window) *window = s->peer_window;
+  s->peer_world   = world;
+  s->peer_rank    = rank;
+  s->peer_n_total = n_total;
+  return MRS_OK;
+}
+
+int mrs_swarm_comm_init_peer(mrs_swarm_t* s, void* const* windows, const uint8_t* ipc_handles) {
+  MRS_ENTER(s);
+  if (!s || s->peer_world == 0) return fail(MRS_ERR_ARG, "mrs_swarm_peer_window_create has not been called");
+  if (!windows && !ipc_handles) return fail(MRS_ERR_ARG, "the peers' windows are needed as pointers or as IPC handles");
+  if (s->comm_world > 0) return fail(MRS_ERR_ARG, "communicator already initialised");
+  HIPCHK(hipSetDevice(s->device));
+  for (int q = 0; q < s->peer_world; q++) {
+    void* p = nullptr;
+    if (q == s->peer_rank) {
+      p = s->peer_window;
+    } else if (windows && windows[q]) {
+      p = windows[q];
+    } else if (ipc_handles) {
+      hipIpcMemHandle_t h;
+      memcpy(&h, ipc_handles + 64 * (size_t)q, 64);
+      const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fail(MRS_ERR_HIP, "peer window of rank " + std::to_string(q) + ": hipIpcOpenMemHandle: " + hipGetErrorString(e));
+      s->peer_opened.push_back(p);
+    } else {
+      return fail(MRS_ERR_ARG, "no window given for rank " + std::to_string(q));
+    }
+    s->peer_windows.win[q] = p;
+  }
+  s->comm_peer = true;
+  s->peer_seq = s->peer_tickets = 0u;
+  const int rc = comm_buffers(s, s->peer_world, s->peer_rank, s->peer_n_total);
+  if (rc) s->comm_peer = false;
+  return rc;
 }
 
 int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, double collective_latency_us, double slab_width) {
@@ -1800,7 +1918,10 @@ int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange) {
 int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   MRS_ENTER(s);
   if (!s) return fail(MRS_ERR_ARG, "null swarm");
-  if (s->comm_world == 0) return MRS_OK;
+  if (s->comm_world == 0) {
+    if (s->peer_window) peer_release(s);  // a window that never became a communicator
+    return MRS_OK;
+  }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   int rc = MRS_OK;
@@ -1810,6 +1931,7 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   s->comm_user  = nullptr;
   s->comm_group = nullptr;
   s->comm_standin = false;
+  peer_release(s);
   s->comm_world = 0;
   s->x_ok       = false;
   mrs_collide_invalidate_gathered(s->cwork);
@@ -2132,6 +2254,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   unsigned w[CTL_WORDS];
   HIPCHK(mrs_collide_fused_words(s->cwork, s->stream, w));
   if (w[CTL_BADSLOT]) return fail(MRS_ERR_HIP, "export-set exchange: a listed foreign UAV is not in its owner's export set (" + std::to_string(w[CTL_BADSLOT]) + " entries)");
+  if (s->peer_err && *s->peer_err) return fail(MRS_ERR_HIP, "peer-window exchange: a rank waited in vain for a peer's block (the results of this call are not valid; the windows are dead: use fresh processes)");
   if (w[CTL_ERROR] & 1u) return fail(MRS_ERR_HIP, "split sharded tick: a launch waited in vain for the launch on the other stream (the results of this call are not valid; the stream and the communicator are dead: use a fresh process)");
   if (w[CTL_ERROR] & 2u) return fail(MRS_ERR_HIP, "split sharded tick: a UAV left its skin without the displacement bound announcing it (DESIGN §5) — the results of this call are not valid; run with MRS_SHARD_SPLIT=0 on every rank and report the case");
   return MRS_OK;
@@ -2163,6 +2286,7 @@ int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t
   else
     rc = full_gather_ticks(s, dt, n_ticks, c);
   if (rc) return rc;
+  if (s->peer_err && *s->peer_err) return fail(MRS_ERR_HIP, "peer-window exchange: a rank waited in vain for a peer's block (the results are not valid; the windows are dead: use fresh processes)");
   s->nbr_dirty = false;
   return finish_profile(s);
 }

@@ -134,6 +134,11 @@ enum {
 #define MRS_BLK_BOUNDARY 1u  // some UAV of the block lists a foreign UAV: the block is stepped by the boundary launch
 #define MRS_BLK_LAYER1   2u  // interior block, some UAV of it lists a UAV of a boundary block: waits for that block's epoch word
 #define MRS_PRED_HORIZON 4u  // steps by which "may leave its skin" is announced ahead (why 4: DESIGN §5)
+// peer-window exchange (collide.hip k_peer_allgather): the windows of all ranks as this process addresses them
+#define MRS_MAX_PEERS 64
+struct MrsPeerWindows {
+  void* win[MRS_MAX_PEERS];
+};
 enum { MRS_PART_FULL = 0, MRS_PART_INTERIOR = 1, MRS_PART_BOUNDARY = 2 };
 
 struct CollDev {

@@ -97,6 +97,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
     "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component", "mrs_debug_pid_update", "mrs_swarm_set_state_pos", "mrs_swarm_set_pid", "mrs_swarm_clone",
     "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
+    "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
 ]
 
@@ -258,6 +259,8 @@ def load_library():
         "mrs_swarm_get_split_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_debug_stream_delay": [vp, C.c_double],
         "mrs_swarm_comm_init_standin": [vp, i32, i32, C.c_int64, C.c_double, C.c_double],
+        "mrs_swarm_peer_window_create": [vp, i32, i32, C.c_int64, C.POINTER(C.c_void_p), C.c_char_p],
+        "mrs_swarm_comm_init_peer": [vp, C.POINTER(C.c_void_p), C.c_char_p],
         "mrs_swarm_set_exchange": [vp, i32],
         "mrs_slab_partition": [dp, C.c_int64, i32, C.POINTER(C.c_int64)],
         "mrs_swarm_get_fused_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
@@ -478,6 +481,24 @@ class Swarm:
     def comm_init_standin(self, world, rank, n_total, collective_latency_us, slab_width):
         """measurement stand-in: this rank alone, its neighbours are images of itself, every collective takes a fixed latency"""
         _check(_lib.mrs_swarm_comm_init_standin(self._h, int(world), int(rank), int(n_total), float(collective_latency_us), float(slab_width)))
+
+    def peer_window_create(self, world, rank, n_total, want_handle=True):
+        """this rank's window of the peer-window exchange: (device address, 64-byte IPC handle or None) — include/mrs_swarm.h"""
+        ptr = C.c_void_p()
+        handle = C.create_string_buffer(64) if want_handle else None
+        _check(_lib.mrs_swarm_peer_window_create(self._h, int(world), int(rank), int(n_total), C.byref(ptr), handle))
+        return int(ptr.value), (handle.raw if want_handle else None)
+
+    def comm_init_peer(self, windows=None, handles=None):
+        """windows: device addresses of every rank's window valid in THIS process (None / 0 entries: use the handle);
+        handles: the ranks' 64-byte IPC handles in rank order"""
+        arr = None
+        if windows is not None:
+            arr = (C.c_void_p * len(windows))(*[C.c_void_p(int(w) if w else 0) for w in windows])
+        blob = None
+        if handles is not None:
+            blob = b"".join(h if h is not None else bytes(64) for h in handles)
+        _check(_lib.mrs_swarm_comm_init_peer(self._h, arr, blob))
 
     def debug_chaos(self, max_sleep_us, seed=1):
         _check(_lib.mrs_swarm_debug_chaos(self._h, int(max_sleep_us), int(seed)))
