@@ -277,8 +277,9 @@ int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int
  *       device with peer access enabled), otherwise `ipc_handles + 64 q` is opened.  The entries of the own rank are ignored.
  * Afterwards mrs_swarm_tick_sharded_n / mrs_swarm_comm_destroy as with any other backend (destroy only after every rank's last
  * tick call has returned: peers write into the window until then).  A rank that waits 10 s for a peer's block gives up and the
- * call returns MRS_ERR_HIP.  Ranks in one process on ONE device (tests) need a hardware queue per rank: GPU_MAX_HW_QUEUES >= 2 * world
- * in the environment before the HIP runtime starts — kernels of different ranks wait for each other on the device. */
+ * call returns MRS_ERR_HIP.  Ranks of one process must sit on DIFFERENT devices (peer access enabled by the caller): on one device the
+ * kernels of different ranks wait for each other, and any runtime call of one rank's host that waits for the whole device (hipFree in a
+ * search that grows a buffer) then waits for a peer's kernel that waits for this rank. */
 int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, int64_t n_total, void** window, uint8_t* ipc_handle64);
 int mrs_swarm_comm_init_peer(mrs_swarm_t* s, void* const* windows, const uint8_t* ipc_handles);
 int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange);

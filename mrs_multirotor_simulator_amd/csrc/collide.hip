@@ -1357,7 +1357,11 @@ __global__ __launch_bounds__(MRS_PEER_THREADS) void k_peer_allgather(MrsPeerWind
     const long long t0   = wall_clock64();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (wall_clock64() - t0 > MRS_WAIT_TICKS) {
-        __hip_atomic_store((peer_u32*)err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (pinned host word: a plain store, no PCIe atomic)
+        // (pinned host words, plain stores — no PCIe atomic: [0] = set, [1] = the collective, [2] = the peer, [3] = what its flag said)
+        __hip_atomic_store((peer_u32*)err_host + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((peer_u32*)err_host + 2, (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((peer_u32*)err_host + 3, __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((peer_u32*)err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);

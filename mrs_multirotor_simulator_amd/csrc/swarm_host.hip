@@ -1654,6 +1654,14 @@ int peer_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
   return MRS_OK;
 }
 
+int peer_failed(mrs_swarm* s) {
+  volatile unsigned* e = s->peer_err;
+  return fail(MRS_ERR_HIP, "peer-window exchange: rank " + std::to_string(s->comm_rank) + " waited in vain for the block of rank " + std::to_string(e[2]) +
+                               " in collective " + std::to_string(e[1]) + " (that rank's flag says " + std::to_string(e[3]) + "; this rank has issued " +
+                               std::to_string(s->peer_seq) + " collectives, " + std::to_string(s->x_ticks) + " ticks, " + std::to_string(s->x_searches) +
+                               " searches) — the results of this call are not valid and the windows are dead: use fresh processes");
+}
+
 int comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
   if (s->comm_peer) return peer_allgather(s, send, recv, bytes);
   if (s->comm_standin) return standin_allgather(s, send, recv, bytes);
@@ -1742,6 +1750,8 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
   const int64_t n_max = (n_total + world - 1) / world > 0 ? (n_total + world - 1) / world : 1;
   size_t slot = sizeof(PosRecord) * (size_t)n_max;
   if (slot < sizeof(uint32_t) * (size_t)(n_max + 2)) slot = sizeof(uint32_t) * (size_t)(n_max + 2);
+  // (an export block is header + capacity records of 32 B, the capacity up to 1.5 x the largest export set + 127: export_search)
+  if (slot < sizeof(Pos4) * ((size_t)n_max + (size_t)n_max / 2 + 129)) slot = sizeof(Pos4) * ((size_t)n_max + (size_t)n_max / 2 + 129);
   slot = (slot + 255) / 256 * 256;
   s->peer_slot_bytes   = slot;
   s->peer_window_bytes = 4096 + 2 * (size_t)world * slot;
@@ -2254,7 +2264,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   unsigned w[CTL_WORDS];
   HIPCHK(mrs_collide_fused_words(s->cwork, s->stream, w));
   if (w[CTL_BADSLOT]) return fail(MRS_ERR_HIP, "export-set exchange: a listed foreign UAV is not in its owner's export set (" + std::to_string(w[CTL_BADSLOT]) + " entries)");
-  if (s->peer_err && *s->peer_err) return fail(MRS_ERR_HIP, "peer-window exchange: a rank waited in vain for a peer's block (the results of this call are not valid; the windows are dead: use fresh processes)");
+  if (s->peer_err && *s->peer_err) return peer_failed(s);
   if (w[CTL_ERROR] & 1u) return fail(MRS_ERR_HIP, "split sharded tick: a launch waited in vain for the launch on the other stream (the results of this call are not valid; the stream and the communicator are dead: use a fresh process)");
   if (w[CTL_ERROR] & 2u) return fail(MRS_ERR_HIP, "split sharded tick: a UAV left its skin without the displacement bound announcing it (DESIGN §5) — the results of this call are not valid; run with MRS_SHARD_SPLIT=0 on every rank and report the case");
   return MRS_OK;
@@ -2286,7 +2296,7 @@ int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t
   else
     rc = full_gather_ticks(s, dt, n_ticks, c);
   if (rc) return rc;
-  if (s->peer_err && *s->peer_err) return fail(MRS_ERR_HIP, "peer-window exchange: a rank waited in vain for a peer's block (the results are not valid; the windows are dead: use fresh processes)");
+  if (s->peer_err && *s->peer_err) return peer_failed(s);
   s->nbr_dirty = false;
   return finish_profile(s);
 }

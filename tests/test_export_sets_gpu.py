@@ -45,12 +45,10 @@ def run_ranks(fns):
 class VirtualShards:
     """`world` shards of one swarm given in PUBLIC index order; order[k] = public index at sorted position k"""
 
-    def __init__(self, M, world, order, po, pos, heading, st, mode, cmd, arith, exchange, rendezvous=False, transport="loopback"):
-        """transport: "loopback" (the in-process group: host-driven copies) or "peer" (peer-window exchange: the ranks' kernels write
-        into each other's windows — needs a hardware queue per rank, see tests/test_peer_window_gpu.py)"""
+    def __init__(self, M, world, order, po, pos, heading, st, mode, cmd, arith, exchange, rendezvous=False):
         from mrs_multirotor_simulator_amd.sharded import shard_range
         self.M, self.world, self.order, self.n_total = M, world, order, len(order)
-        self.group = M.LoopbackGroup(world) if transport == "loopback" else None
+        self.group = M.LoopbackGroup(world)
         if rendezvous:
             self.group.set_rendezvous(True)
         self.shards = []
@@ -62,15 +60,9 @@ class VirtualShards:
                 g.construct(0, hi - lo, po, None if pos is None else pos[idx], None if heading is None else heading[idx])
                 g.set_state(0, hi - lo, st["x"][idx], st["v"][idx], st["R"][idx], st["omega"][idx], st["motor_rpm"][idx])
                 g.set_input(0, hi - lo, mode, cmd[idx])
-            if transport == "loopback":
-                g.comm_init_loopback(self.group, r, self.n_total)
-                g.set_exchange(exchange)
+            g.comm_init_loopback(self.group, r, self.n_total)
+            g.set_exchange(exchange)
             self.shards.append((g, idx))
-        if transport == "peer":
-            windows = [g.peer_window_create(world, r, self.n_total, want_handle=False)[0] for r, (g, _) in enumerate(self.shards)]
-            for g, _ in self.shards:
-                g.comm_init_peer(windows=windows)
-                g.set_exchange(exchange)
 
     def tick_n(self, n, enabled, crash, rebounce):
         run_ranks([(lambda g=g: g.tick_sharded_n(DT, n, enabled, crash, rebounce)) for g, _ in self.shards])

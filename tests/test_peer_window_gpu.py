@@ -1,14 +1,16 @@
 """The peer-window exchange (include/mrs_swarm.h: mrs_swarm_peer_window_create / mrs_swarm_comm_init_peer; csrc/collide.hip
-k_peer_allgather): the collectives of the sharded tick as direct device-to-device writes with device-side signalling.
-  * ranks in ONE process (pointers), each on its own host thread, hosts skewed, split ticks — in a child process, because a hardware
-    queue per rank has to be asked for before the HIP runtime starts (kernels of different ranks wait for each other on the device;
-    two of them behind each other in one queue would wait for ever, i.e. for the 10 s after which the exchange gives up);
-  * ranks in SEPARATE processes on the one GPU (IPC handles carried over gloo): separate address spaces, windows mapped with
-    hipIpcOpenMemHandle — the form a multi-GPU node runs, one hop shorter.
-Both against the single-swarm oracle, UAV by UAV."""
+k_peer_allgather): the collectives of the sharded tick as direct device-to-device writes with device-side signalling, no collective
+library and no host in the tick.  Ranks in SEPARATE processes on the one GPU of the test box — the form a multi-GPU node runs, one
+xGMI hop shorter: separate address spaces and HIP contexts, windows mapped with hipIpcOpenMemHandle, the 64-byte handles the only
+thing the hosts ever tell each other (over gloo).  Hosts skewed by mrs_swarm_debug_chaos (random sleeps, stale word views — nothing
+couples the hosts any more, so they drift as far as the protocol lets them), ticks in the split form, calls of uneven length, one
+tick in crash mode; every rank against the single-swarm oracle, UAV by UAV.
+
+(Ranks of ONE process on ONE device are not a test bed for this backend: the kernels of different ranks wait for each other on the
+device, and any runtime call of one rank's host that waits for the whole device — hipFree in a search that grows a buffer — then
+waits for a peer's kernel that waits for this rank: 10 s later the exchange gives up.  Measured with tools/peer_rank_pair.py.)"""
 import os
 import socket
-import subprocess
 import sys
 
 import numpy as np
@@ -20,23 +22,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 pytestmark = pytest.mark.gpu
 DT = 0.001
+BLOCKS = [(41, False), (1, True), (118, False), (80, False)]  # ticks, crash mode: 240 ticks
 
 
-@pytest.mark.parametrize("world,n_total,chaos_us", [(2, 3001, 0), (4, 5000, 300)])
-def test_peer_window_ranks_of_one_process(world, n_total, chaos_us):
-    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(4 * world))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "peer_window_worker.py"), str(world), str(n_total), str(chaos_us)], env=env,
-                       capture_output=True, text=True, timeout=600)
-    print(r.stdout[-2000:], r.stderr[-3000:])
-    assert r.returncode == 0 and "PEER-WINDOW OK" in r.stdout
-
-
-BLOCKS = [(60, False), (1, True), (59, False)]
-
-
-def _ipc_worker(rank, world, port, n_total, out_dir):
+def _ipc_worker(rank, world, port, n_total, shards, chaos_us, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["MRS_SHARD_SPLIT_MIN_BLOCKS"] = "1"      # (read when a swarm is created: small shards take the split form too)
+    os.environ["MRS_SHARD_SPLIT_MAX_FRACTION"] = "0.95"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import helpers
     import mrs_multirotor_simulator_amd as M
@@ -44,7 +37,7 @@ def _ipc_worker(rank, world, port, n_total, out_dir):
     from test_sharded_multiprocess_gpu import _scenario
     M.load_library()
     pos, st, cmd = _scenario(n_total)
-    order = M.slab_partition(pos, world)
+    order = M.slab_partition(pos, world) if shards == "slabs" else np.arange(n_total)
     lo, hi = shard_range(n_total, world, rank)
     idx = order[lo:hi]
     po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
@@ -56,29 +49,32 @@ def _ipc_worker(rank, world, port, n_total, out_dir):
     handles = [None] * world
     dist.all_gather_object(handles, handle)  # the only thing the hosts ever tell each other
     g.comm_init_peer(handles=handles)
+    if chaos_us > 0:
+        g.debug_chaos(chaos_us, seed=31 * world + rank)
     for n, crash in BLOCKS:
         g.tick_sharded_n(DT, n, True, crash, 100.0)
     s = g.get_state()
     ci = g.comm_info()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, x=s["x"], v=s["v"], R=s["R"], omega=s["omega"], motor_rpm=s["motor_rpm"],
-             f=g.get_external_force(), crashed=g.has_crashed(), searches=ci["searches"], ticks=ci["ticks"])
+             f=g.get_external_force(), crashed=g.has_crashed(), searches=ci["searches"], ticks=ci["ticks"], split=g.split_stats()[0],
+             bytes_per_tick=ci["bytes_per_tick"], bytes_per_rebuild=ci["bytes_per_rebuild"])
     dist.barrier()  # nobody unmaps a window a peer may still write into
     g.comm_destroy()
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,shards,chaos_us", [(2, "slabs", 0), (3, "slabs", 300), (4, "slabs", 300), (3, "index", 100)])
+def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world, shards, chaos_us):
     import torch.multiprocessing as mp
     import helpers
     from helpers import RTOL_LITERAL
     from test_sharded_multiprocess_gpu import _scenario
-    n_total = 3001
+    n_total = 3001 if shards == "slabs" else 1800
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_ipc_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_ipc_worker, args=(world, port, n_total, shards, chaos_us, str(tmp_path)), nprocs=world, join=True)
     pos, st, cmd = _scenario(n_total)
     o = oracle.OracleSwarm(n_total)
     o.construct(0, n_total, helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0), pos, np.zeros(n_total))
@@ -92,7 +88,7 @@ def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world):
         n_ticks += n
     so, fo, co = o.get_state(), o.get_external_force(), o.has_crashed()
     assert co.sum() > 0 and (np.abs(fo).sum(axis=1) > 0).sum() > 20
-    covered = np.zeros(n_total, dtype=bool)
+    covered, split = np.zeros(n_total, dtype=bool), []
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         idx = d["idx"]
@@ -101,5 +97,9 @@ def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world):
         helpers.assert_close(d["f"], fo[idx], 1e-11, f"rank {r}: forces")
         for k in ("x", "v", "R", "omega", "motor_rpm"):
             helpers.assert_close(d[k], so[k][idx], RTOL_LITERAL, f"rank {r}: {k}")
-        assert int(d["ticks"]) == n_ticks and 2 <= int(d["searches"]) <= n_ticks // 3
+        assert int(d["ticks"]) == n_ticks and 2 <= int(d["searches"]) <= n_ticks // 2, (int(d["ticks"]), int(d["searches"]))
+        split.append(int(d["split"]))
     assert covered.all()
+    if shards == "slabs":
+        assert sum(split) > 20 * world, split  # the split form really ran (the 4 ticks after every search and call are serial)
+    print(f"peer windows, {world} processes, {shards}, chaos {chaos_us} us: split ticks {split}")

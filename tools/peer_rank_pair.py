@@ -2,6 +2,9 @@
 """Two ranks of a sharded swarm in ONE process on the one GPU, bound by the peer-window exchange (or, for comparison, by the
 in-process loopback group): what the exchange kernel itself costs (rocprofv3 --kernel-trace: k_peer_allgather) at the export-block
 sizes of a real shard.  Both ranks' launches share the device, so the tick time printed here is two ranks' work, not one's.
+(Not a supported deployment — ranks of one process belong on different devices: here a hipFree of one rank's host during a search waits
+for the whole device, i.e. for the peer's exchange kernel, which waits for this rank; when that happens the exchange gives up after 10 s
+and the run ends with the library's error.  Most runs get through, and the kernel trace is what this tool is for.)
 usage: peer_rank_pair.py [n_per_shard] [ticks] [peer|loopback]"""
 import os, sys, threading, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # a hardware queue per rank and stream: the ranks' kernels wait for each other on the device
