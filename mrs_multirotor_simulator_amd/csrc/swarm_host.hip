@@ -1755,13 +1755,16 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
   slot = (slot + 255) / 256 * 256;
   s->peer_slot_bytes   = slot;
   s->peer_window_bytes = 4096 + 2 * (size_t)world * slot;
-  // fine-grained: written by other devices while kernels of this one read it (MRS_PEER_WINDOW_COARSE=1: ordinary device memory,
-  // for runtimes that cannot export fine-grained allocations — every access of the exchange kernel is system-scope either way)
-  const char* coarse = getenv("MRS_PEER_WINDOW_COARSE");
-  if (coarse && atoi(coarse) != 0)
+  // Written by other devices WHILE kernels of this one poll and read it: uncached device memory ("extended-scope fine-grained" — on
+  // this GPU family plain fine-grained memory is only guaranteed coherent across devices at kernel boundaries, and the flags are
+  // polled inside a kernel; collective libraries allocate their flag and staging memory the same way).  MRS_PEER_WINDOW_MEMORY =
+  // finegrained | coarse for runtimes that cannot export an uncached allocation (every access of the exchange kernel is
+  // system-scope either way).
+  const char* kind = getenv("MRS_PEER_WINDOW_MEMORY");
+  if (kind && strcmp(kind, "coarse") == 0)
     HIPCHK(hipMalloc(&s->peer_window, s->peer_window_bytes));
   else
-    HIPCHK(hipExtMallocWithFlags(&s->peer_window, s->peer_window_bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipExtMallocWithFlags(&s->peer_window, s->peer_window_bytes, kind && strcmp(kind, "finegrained") == 0 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
   HIPCHK(hipMalloc((void**)&s->peer_ticket, sizeof(unsigned) * MRS_MAX_PEERS));
   HIPCHK(hipHostMalloc((void**)&s->peer_err, 64, hipHostMallocMapped));
   *s->peer_err = 0u;
