@@ -64,13 +64,14 @@ def _ipc_worker(rank, world, port, n_total, shards, chaos_us, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shards,chaos_us", [(2, "slabs", 0), (3, "slabs", 300), (4, "slabs", 300), (3, "index", 100)])
-def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world, shards, chaos_us):
+# (12 000 UAVs on 2 ranks: the search's full gather is 288 KB per rank — several blocks per peer and the ticket path of the exchange kernel)
+@pytest.mark.parametrize("world,shards,chaos_us,n_total", [(2, "slabs", 0, 3001), (3, "slabs", 300, 3001), (4, "slabs", 300, 3001), (3, "index", 100, 1800),
+                                                          (2, "slabs", 100, 12000)])
+def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world, shards, chaos_us, n_total):
     import torch.multiprocessing as mp
     import helpers
     from helpers import RTOL_LITERAL
     from test_sharded_multiprocess_gpu import _scenario
-    n_total = 3001 if shards == "slabs" else 1800
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
