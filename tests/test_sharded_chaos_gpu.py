@@ -60,6 +60,40 @@ def test_sharded_ticks_under_host_skew(mrs, oracle, monkeypatch, world, rendezvo
           f"ticks replayed {[ci['noop_ticks'] for ci in info]}, split ticks / boundary blocks {split}")
 
 
+def test_split_ticks_on_reserved_compute_units(mrs, oracle, monkeypatch):
+    """MRS_SPLIT_CU_RESERVE (boundary chain and collective on a CU-masked stream of their own, interior launch on the other CUs —
+    a switch, off by default: MEASUREMENTS §5.6): two more streams, same results."""
+    M = mrs
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MIN_BLOCKS", "1")
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MAX_FRACTION", "0.95")
+    monkeypatch.setenv("MRS_SPLIT_CU_RESERVE", "32")
+    world, n_total = 2, 3000
+    rng = np.random.default_rng(78)
+    pos, st, cmd = moving_swarm(rng, n_total, speed=5.0)
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    o = oracle.OracleSwarm(n_total)
+    o.construct(0, n_total, po, pos, np.zeros(n_total))
+    o.set_state(0, n_total, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    o.set_input(0, n_total, oracle.ACTUATOR_CMD, cmd)
+    order = M.slab_partition(pos, world)
+    vs = VirtualShards(M, world, order, helpers.to_product_params(M, po), pos, np.zeros(n_total), st, M.ACTUATOR_CMD, cmd, M.ARITH_LITERAL,
+                       M.EXCHANGE_EXPORT_SETS, rendezvous=True)
+    done = 0
+    for n in (50, 3, 97):
+        vs.tick_n(n, True, False, 100.0)
+        for _ in range(n):
+            o.step(DT)
+            o.handle_collisions(True, False, 100.0)
+        done += n
+        a, so = vs.gather(), o.get_state()
+        helpers.assert_close(a["f"], o.get_external_force(), 1e-11, f"forces after {done} ticks")
+        for k in ("x", "v", "R", "omega", "motor_rpm"):
+            helpers.assert_close(a[k], so[k], RTOL_LITERAL, f"{k} after {done} ticks")
+    split = [g.split_stats()[0] for g, _ in vs.shards]
+    vs.close()
+    assert min(split) > 60, split
+
+
 def test_split_ticks_when_the_displacement_bound_cannot_be_given(mrs, oracle, monkeypatch):
     """A motor speed beyond the airframe's max_rpm (set through set_state) voids the thrust cap behind the announcements: that rank
     announces on every tick (searches every few ticks) — slower, and still exactly the oracle's results."""
