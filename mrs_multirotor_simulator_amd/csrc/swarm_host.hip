@@ -309,6 +309,7 @@ struct mrs_swarm {
   // every C-ABI call bumps op_seq (MRS_LOCK); mrs_swarm_synchronize notes the value it leaves behind: a run of steps that is the very
   // next call finds both streams idle and starts its second stream without the fork event
   uint64_t    op_seq = 0, quiet_seq = ~0ull;
+  mutable bool stream_exported = false;  // mrs_swarm_stream has handed the stream to the caller, who may enqueue work behind the library's back
   bool        split_steps = true;  // tuning: MRS_SPLIT_STREAMS=0
   // native multi-GPU collision exchange (mrs_swarm_comm_init): RCCL all-gather issued on `stream`
   void*      rccl_comm = nullptr;
@@ -846,6 +847,7 @@ int mrs_swarm_stream(const mrs_swarm_t* s, void** stream) {
   MRS_LOCK(s);
   if (!s || !stream) return fail(MRS_ERR_ARG, "null argument");
   *stream = (void*)s->stream;
+  s->stream_exported = true;
   return MRS_OK;
 }
 
@@ -1365,6 +1367,10 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   HIPCHK(hipSetDevice(s->device));
   int rc = upload_types(s, dt);
   if (rc) return rc;
+  // (a caller holding the handle of mrs_swarm_stream() may have enqueued work of its own without an ABI call: then the stream is
+  //  asked — BEFORE the profile's start event goes onto it.  Only then: the query itself puts a marker on the stream, which costs
+  //  the run that follows ~12 us — 0.6 us per step of a 20-step region, measured)
+  const bool idle_at_entry = s->quiet_seq + 1 == s->op_seq && (!s->stream_exported || hipStreamQuery(s->stream) == hipSuccess);
   if ((rc = begin_profile(s))) return rc;
   bool enqueued = false;  // something of this call is already on the stream
   if (s->collide_since_step && substeps_per_launch == 1) {  // the first step of the run may carry a collision tick
@@ -1380,9 +1386,8 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
     static const int split_min_blocks = getenv("MRS_SPLIT_MIN_BLOCKS") ? atoi(getenv("MRS_SPLIT_MIN_BLOCKS")) : 1024;  // tuning aid
     const bool split = s->split_steps && s->profiling != 2 && (s->n + 63) / 64 >= split_min_blocks && (n_steps + substeps_per_launch - 1) / substeps_per_launch >= 4;
     // (the call right before this one was mrs_swarm_synchronize and nothing has been enqueued since — not even by the lines above:
-    //  both streams are idle (upload_types synchronises when it copies), the second one needs no event to wait for;
-    //  a caller holding the handle of mrs_swarm_stream() may have enqueued work of its own without an ABI call: the query sees that)
-    const bool quiet = s->quiet_seq + 1 == s->op_seq && !enqueued && hipStreamQuery(s->stream) == hipSuccess;
+    //  both streams are idle (upload_types synchronises when it copies), the second one needs no event to wait for)
+    const bool quiet = idle_at_entry && !enqueued;
     if (split && !quiet && (rc = fork_streams(s))) return rc;
     int left = n_steps;
     while (left > 0 && rc == MRS_OK) {
