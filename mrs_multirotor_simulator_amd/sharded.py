@@ -25,6 +25,26 @@ def max_shard(n_total, world):
     return math.ceil(n_total / world)
 
 
+def bind_native_exchange(swarm, n_total, transport="rccl", group=None):
+    """Binds the library's OWN sharded tick (mrs_swarm_tick_sharded_n) to the ranks of a torch.distributed job, one swarm per rank:
+    "rccl" — an RCCL communicator of the library's own (the 128-byte id travels over `group`);
+    "peer" — the peer-window exchange (direct writes into the peers' device memory; the 64-byte IPC handles travel over `group`).
+    Afterwards `swarm.tick_sharded_n(...)` on every rank; `dist.barrier()` before `swarm.comm_destroy()` (peer windows)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if transport == "peer":
+        _, handle = swarm.peer_window_create(world, rank, n_total)
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+        swarm.comm_init_peer(handles=handles)
+        return
+    if transport != "rccl":
+        raise ValueError(f"unknown transport {transport!r}")
+    from .swarm import rccl_unique_id
+    box = [bytes(rccl_unique_id()) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    swarm.comm_init(world, rank, box[0], n_total)
+
+
 class GpuEngine:
     """Adapter of mrs_multirotor_simulator_amd.Swarm to the three calls ShardedSwarm needs."""
 

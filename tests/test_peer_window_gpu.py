@@ -45,10 +45,8 @@ def _ipc_worker(rank, world, port, n_total, shards, chaos_us, out_dir):
     g.construct(0, hi - lo, helpers.to_product_params(M, po), pos[idx], np.zeros(hi - lo))
     g.set_state(0, hi - lo, st["x"][idx], st["v"][idx], st["R"][idx], st["omega"][idx], st["motor_rpm"][idx])
     g.set_input(0, hi - lo, M.ACTUATOR_CMD, cmd[idx])
-    _, handle = g.peer_window_create(world, rank, n_total)
-    handles = [None] * world
-    dist.all_gather_object(handles, handle)  # the only thing the hosts ever tell each other
-    g.comm_init_peer(handles=handles)
+    from mrs_multirotor_simulator_amd.sharded import bind_native_exchange
+    bind_native_exchange(g, n_total, "peer")  # window + IPC handle, all-gather of the handles over gloo: the only thing the hosts ever tell each other
     if chaos_us > 0:
         g.debug_chaos(chaos_us, seed=31 * world + rank)
     for n, crash in BLOCKS:
