@@ -70,6 +70,35 @@ def test_bench_launch_against_oracle(mrs, oracle, workload, n, steps):
     assert np.allclose(np.einsum("nij,nik->njk", full["R"], full["R"]), np.eye(3), atol=1e-9)
 
 
+@pytest.mark.parametrize("exported", [False, True])
+def test_bench_regions_of_twenty_steps(mrs, oracle, exported):
+    """The driver's `bench.py --steps 20 --warmup 5`: regions of 20 steps, each behind mrs_swarm_synchronize.  A run of steps that
+    follows a synchronize starts its second stream WITHOUT the fork event (both streams are idle); once the caller holds the
+    stream's handle (mrs_swarm_stream) the library asks the stream first.  Both ways against the oracle."""
+    M = mrs
+    n, regions = 100_000, 6
+    rng = np.random.default_rng(12)
+    st, cmd = _bench_inputs(n, "position", seed=3)
+    g = M.Swarm(n, arith=M.ARITH_FAST)
+    g.construct(0, n, M.model_params("x500", ground_enabled=True))
+    g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    g.set_input(0, n, M.POSITION_CMD, cmd)
+    if exported:
+        assert g.stream()
+    g.step_n(DT, 5)
+    for _ in range(regions):
+        g.synchronize()
+        g.step_n(DT, 20)
+    g.synchronize()
+    nb = (n + 63) // 64
+    pick = np.unique(np.concatenate([np.sort(rng.choice(n, 1024, replace=False)), [0, (nb // 2) * 64 - 1, (nb // 2) * 64, n - 1]]))
+    ref = _oracle_sample(oracle, st, cmd, pick, oracle.POSITION_CMD, 5 + 20 * regions)
+    got, _ = _gpu_sample(g, pick)
+    for k in ("x", "v", "R", "omega", "motor_rpm", "pid"):
+        helpers.assert_close(got[k], ref[k], RTOL_NORTH_STAR, f"regions of 20, exported={exported}: {k}")
+    helpers.assert_close_per_uav(got, ref, RTOL_NORTH_STAR, f"regions of 20, exported={exported}")
+
+
 # ---- BASELINE config 4 in the form `bench.py --workload position+collisions` (and its `config4` sub-record) times ----------------
 def _tainted(x_all, in_sample, tainted, reach):
     """One checkpoint of the closure argument: sample UAVs with an OUTSIDE UAV within `reach` become tainted, and taint spreads
