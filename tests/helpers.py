@@ -57,10 +57,13 @@ class Pair:
         self.o.step_n(dt, n)
         self.g.step_n(dt, n)
 
-    def compare(self, rtol, what="", fields=("x", "v", "v_prev", "R", "omega", "motor_rpm")):
+    def compare(self, rtol, what="", fields=("x", "v", "v_prev", "R", "omega", "motor_rpm"), mask=None):
+        """mask: boolean per UAV — only these rows are compared (campaigns that have to leave diverging closed loops out)"""
         a, b = self.g.get_state(), self.o.get_state()
         a["imu"], b["imu"] = self.g.get_imu(), self.o.get_imu()
         a["pid"], b["pid"] = self.g.get_pid(), self.o.get_pid()
+        if mask is not None:
+            a, b = {k: v[mask] for k, v in a.items()}, {k: v[mask] for k, v in b.items()}
         worst = 0.0
         for k in tuple(fields) + ("imu", "pid"):
             worst = max(worst, assert_close(a[k], b[k], rtol, f"{what}:{k}"))
