@@ -2,7 +2,7 @@
 """More seeds of tests/test_sharded_chaos_gpu.py: the lock-free sharded protocol (split ticks, announced stall indices) under host
 skew, `runs` scenarios with random world size (2..8), swarm size, speeds, chaos amplitude, loopback mode and call lengths, each
 against the oracle (LITERAL, 1e-11).  A protocol slip is a collective mismatch / time-out, a missed stall a wrong force.
-usage: chaos_seeds.py [runs] [first_seed]"""
+usage: chaos_seeds.py [runs] [first_seed] [min UAVs per rank, default 600] [max, default 1200]"""
 import os
 import sys
 import time
@@ -22,11 +22,13 @@ from test_export_sets_gpu import DT, VirtualShards, moving_swarm  # noqa: E402
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+per_lo = int(sys.argv[3]) if len(sys.argv) > 3 else 600
+per_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 1200
 M.load_library()
 for seed in range(first, first + runs):
     rng = np.random.default_rng(70_000 + seed)
     world = int(rng.integers(2, 9))
-    n_total = int(rng.integers(600, 1200)) * world
+    n_total = int(rng.integers(per_lo, per_hi)) * world
     speed = float(rng.uniform(3.0, 9.0))
     chaos = int(rng.choice([0, 50, 300, 1000]))
     rendezvous = bool(rng.integers(0, 2))
