@@ -432,6 +432,64 @@ def sub_record(rec):
     return {k: rec[k] for k in SUB_KEYS if k in rec}
 
 
+def sharded_rank_cost(n_per_rank=125_000, world=8, ticks=600, latency_us=20.0, split=True, warm=80, volume_per_uav=64.0):
+    """Device time ONE rank of a `world`-rank config-5 run spends per tick: rank world/2 alone on this GPU with the library's measurement
+    stand-in for the collective (mrs_swarm_comm_init_standin): every collective takes `latency_us` of stream time and the rank's
+    neighbours in the slab order are periodic images of itself — boundary sets, boundary / interior launches, searches and buffer
+    sizes of the real run; missing: the other ranks' physics and the wire.  split=False: round 2's serial protocol (MRS_SHARD_SPLIT=0)."""
+    import mrs_multirotor_simulator_amd as M
+    from mrs_multirotor_simulator_amd.sharded import shard_range
+    rank, n_total = world // 2, n_per_rank * world
+    st, cmd = make_inputs(n_total, "position+collisions", seed=5, volume_per_uav=volume_per_uav)
+    order = M.slab_partition(st["x"], world)
+    lo, hi = shard_range(n_total, world, rank)
+    idx = order[lo:hi]
+    width = float(st["x"][idx, 0].max() - st["x"][idx, 0].min()) * (1.0 + 1.0 / len(idx))
+    before = os.environ.get("MRS_SHARD_SPLIT")
+    if not split:
+        os.environ["MRS_SHARD_SPLIT"] = "0"  # (read when the swarm is created)
+    try:
+        g = M.Swarm(hi - lo, arith=M.ARITH_FAST)
+    finally:
+        if not split:
+            if before is None:
+                os.environ.pop("MRS_SHARD_SPLIT", None)
+            else:
+                os.environ["MRS_SHARD_SPLIT"] = before
+    g.construct(0, hi - lo, M.model_params("x500", ground_enabled=True))
+    g.set_state(0, hi - lo, st["x"][idx], st["v"][idx], st["R"][idx], st["omega"][idx], st["motor_rpm"][idx])
+    g.set_input(0, hi - lo, M.POSITION_CMD, cmd[idx])
+    del st, cmd
+    g.comm_init_standin(world, rank, n_total, latency_us, width)
+    g.tick_sharded_n(DT, warm, True, False, 100.0)
+    g.synchronize()
+    s0, _ = g.split_stats()
+    c0 = g.comm_info()
+    t0 = time.perf_counter()
+    g.tick_sharded_n(DT, ticks, True, False, 100.0)
+    g.synchronize()
+    el = time.perf_counter() - t0
+    ci = g.comm_info()
+    s1, nbnd = g.split_stats()
+    out = {"us_per_tick": el / ticks * 1e6, "ticks": ticks, "rank": rank, "world": world, "uavs_per_rank": hi - lo, "collective_latency_us": latency_us,
+           "form": "split" if split else "serial", "split_ticks": int(s1 - s0), "boundary_blocks": int(nbnd), "blocks": (hi - lo + 63) // 64,
+           "export_set": int(ci["export_count"]), "export_capacity": int(ci["export_capacity"]), "searches": int(ci["searches"] - c0["searches"]),
+           "replayed_noop_ticks": int(ci["noop_ticks"] - c0["noop_ticks"])}
+    g.comm_destroy()
+    del g
+    return out
+
+
+def sharded_rank_record(args):
+    """sub-record of the default line: what one rank of an 8-rank config-5 run costs per tick at 10 and 20 us of collective latency
+    (split form, and the serial form at 10 us) — the figures DESIGN §5 and BASELINE.md quote, reproducible from the driver's own run"""
+    runs = [sharded_rank_cost(latency_us=10.0, ticks=400), sharded_rank_cost(latency_us=20.0, ticks=400), sharded_rank_cost(latency_us=10.0, ticks=400, split=False)]
+    return {"workload": "one rank (rank 4) of 8 x 125000 UAVs of BASELINE configs[4] alone on the GPU, stand-in collective of fixed latency with periodic-image "
+                        "neighbours (mrs_swarm_comm_init_standin): NOT a multi-GPU measurement",
+            "unit": "us per tick (wall clock over the call, 400 ticks incl. searches)",
+            "split_10us": runs[0]["us_per_tick"], "split_20us": runs[1]["us_per_tick"], "serial_10us": runs[2]["us_per_tick"], "runs": runs}
+
+
 def config5_leg(args, R):
     """BASELINE configs[4]: `--config5-uavs` UAVs (1 000 000) with mutual collisions, sharded over the ranks; the collision exchange is
     issued by the library itself on the swarm's stream (mrs_swarm_tick_sharded_n: RCCL bound at run time)."""
@@ -531,6 +589,7 @@ def main():
         out["hbm_streaming"] = sub_record(rec)
         rec, _, _ = step_leg(args, R, 100_000, "position+collisions", 300, 100, traffic=live.get((100_000, "position+collisions"), no_traffic), min_ms=30.0)
         out["config4"] = sub_record(rec)
+        out["sharded_rank_standin"] = sharded_rank_record(args)
 
     import threading
     emit_lock, emitted = threading.Lock(), []
