@@ -1355,7 +1355,10 @@ __global__ __launch_bounds__(MRS_PEER_THREADS) void k_peer_allgather(MrsPeerWind
     // 3. wait
     const peer_u32* flag = (const peer_u32*)((const char*)pw.win[rank] + 64 * q);
     const long long t0   = wall_clock64();
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    // (an exchange of this rank has given up before: the results are void already, the call will say so — what is still queued
+    //  must not wait its 10 s again, launch after launch)
+    const bool dead = __hip_atomic_load((peer_u32*)err_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    while (!dead && (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (wall_clock64() - t0 > MRS_WAIT_TICKS) {
         // (pinned host words, plain stores — no PCIe atomic: [0] = set, [1] = the collective, [2] = the peer, [3] = what its flag said)
         __hip_atomic_store((peer_u32*)err_host + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -2303,8 +2303,9 @@ int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t
     rc = export_ticks(s, dt, n_ticks, c);
   else
     rc = full_gather_ticks(s, dt, n_ticks, c);
-  if (rc) return rc;
+  // (a peer that never answered is the CAUSE of whatever else went wrong behind it — a search over blocks that never arrived, say)
   if (s->peer_err && *s->peer_err) return peer_failed(s);
+  if (rc) return rc;
   s->nbr_dirty = false;
   return finish_profile(s);
 }

@@ -102,3 +102,51 @@ def test_peer_window_ranks_in_separate_processes(tmp_path, oracle, world, shards
     if shards == "slabs":
         assert sum(split) > 20 * world, split  # the split form really ran (the 4 ticks after every search and call are serial)
     print(f"peer windows, {world} processes, {shards}, chaos {chaos_us} us: split ticks {split}")
+
+
+def _lost_peer_worker(rank, world, port, n_total, out_dir):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers
+    import mrs_multirotor_simulator_amd as M
+    from mrs_multirotor_simulator_amd.sharded import bind_native_exchange, shard_range
+    from test_sharded_multiprocess_gpu import _scenario
+    M.load_library()
+    pos, st, cmd = _scenario(n_total)
+    order = M.slab_partition(pos, world)
+    lo, hi = shard_range(n_total, world, rank)
+    idx = order[lo:hi]
+    po = helpers.oracle_params("x500", ground_enabled=True, ground_z=0.0)
+    g = M.Swarm(hi - lo, arith=M.ARITH_LITERAL)
+    g.construct(0, hi - lo, helpers.to_product_params(M, po), pos[idx], np.zeros(hi - lo))
+    g.set_state(0, hi - lo, st["x"][idx], st["v"][idx], st["R"][idx], st["omega"][idx], st["motor_rpm"][idx])
+    g.set_input(0, hi - lo, M.ACTUATOR_CMD, cmd[idx])
+    bind_native_exchange(g, n_total, "peer")
+    g.tick_sharded_n(DT, 30, True, False, 100.0)
+    msg, took = "", 0.0
+    if rank == 0:  # rank 1 stops ticking (a lost rank): this one must come back with an error, not hang, and not 10 s per queued launch
+        t0 = time.time()
+        try:
+            g.tick_sharded_n(DT, 200, True, False, 100.0)
+        except M.MrsError as e:
+            msg = str(e)
+        took = time.time() - t0
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{took:.1f}\n{msg}\n")
+    dist.barrier()  # rank 1 keeps its window mapped until rank 0 is done with it
+    g.comm_destroy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_lost_peer_is_an_error_not_a_hang(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_lost_peer_worker, args=(2, port, 3001, str(tmp_path)), nprocs=2, join=True)
+    took, msg = open(os.path.join(str(tmp_path), "rank0.txt")).read().split("\n")[:2]
+    assert "waited in vain for the block of rank 1" in msg, msg
+    assert 9.0 < float(took) < 45.0, took  # one wait of 10 s on the device (and the host's patience), not one per launch
