@@ -1357,7 +1357,8 @@ __global__ __launch_bounds__(MRS_PEER_THREADS) void k_peer_allgather(MrsPeerWind
     const long long t0   = wall_clock64();
     // (an exchange of this rank has given up before: the results are void already, the call will say so — what is still queued
     //  must not wait its 10 s again, launch after launch)
-    const bool dead = __hip_atomic_load((peer_u32*)err_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    //  (the mark is kept in device memory too — tickets[MRS_MAX_PEERS] —: the pinned host word is a PCIe round trip away)
+    const bool dead = __hip_atomic_load((peer_u32*)(tickets + MRS_MAX_PEERS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     while (!dead && (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (wall_clock64() - t0 > MRS_WAIT_TICKS) {
         // (pinned host words, plain stores — no PCIe atomic: [0] = set, [1] = the collective, [2] = the peer, [3] = what its flag said)
@@ -1365,6 +1366,7 @@ __global__ __launch_bounds__(MRS_PEER_THREADS) void k_peer_allgather(MrsPeerWind
         __hip_atomic_store((peer_u32*)err_host + 2, (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store((peer_u32*)err_host + 3, __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store((peer_u32*)err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((peer_u32*)(tickets + MRS_MAX_PEERS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
       __builtin_amdgcn_s_sleep(2);

@@ -1770,11 +1770,11 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
     HIPCHK(hipMalloc(&s->peer_window, s->peer_window_bytes));
   else
     HIPCHK(hipExtMallocWithFlags(&s->peer_window, s->peer_window_bytes, kind && strcmp(kind, "finegrained") == 0 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
-  HIPCHK(hipMalloc((void**)&s->peer_ticket, sizeof(unsigned) * MRS_MAX_PEERS));
+  HIPCHK(hipMalloc((void**)&s->peer_ticket, sizeof(unsigned) * (MRS_MAX_PEERS + 1)));  // (+ the give-up mark the exchange kernels read)
   HIPCHK(hipHostMalloc((void**)&s->peer_err, 64, hipHostMallocMapped));
   *s->peer_err = 0u;
   HIPCHK(hipMemsetAsync(s->peer_window, 0, 4096, s->stream));  // flags: no collective has happened
-  HIPCHK(hipMemsetAsync(s->peer_ticket, 0, sizeof(unsigned) * MRS_MAX_PEERS, s->stream));
+  HIPCHK(hipMemsetAsync(s->peer_ticket, 0, sizeof(unsigned) * (MRS_MAX_PEERS + 1), s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));  // ... before any peer can learn the address
   if (ipc_handle64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries IPC handles as 64 bytes");
