@@ -2,7 +2,8 @@
 """More seeds of tests/test_sharded_chaos_gpu.py: the lock-free sharded protocol (split ticks, announced stall indices) under host
 skew, `runs` scenarios with random world size (2..8), swarm size, speeds, chaos amplitude, loopback mode and call lengths, each
 against the oracle (LITERAL, 1e-11).  A protocol slip is a collective mismatch / time-out, a missed stall a wrong force.
-usage: chaos_seeds.py [runs] [first_seed] [min UAVs per rank, default 600] [max, default 1200]"""
+usage: chaos_seeds.py [runs] [first_seed] [min UAVs per rank, default 600] [max, default 1200] [literal|fast]
+(fast: the FAST kernels of the split tick — boundary, non-temporal interior — held to 1e-7 over the few hundred ticks of a scenario)"""
 import os
 import sys
 import time
@@ -24,6 +25,8 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 per_lo = int(sys.argv[3]) if len(sys.argv) > 3 else 600
 per_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 1200
+fast = len(sys.argv) > 5 and sys.argv[5] == "fast"
+rtol_state, rtol_force = (1e-7, 1e-7) if fast else (RTOL_LITERAL, 1e-11)
 M.load_library()
 for seed in range(first, first + runs):
     rng = np.random.default_rng(70_000 + seed)
@@ -43,7 +46,7 @@ for seed in range(first, first + runs):
     o.set_state(0, n_total, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
     o.set_input(0, n_total, oracle.ACTUATOR_CMD, cmd)
     order = M.slab_partition(pos, world) if slabs else np.arange(n_total)
-    vs = VirtualShards(M, world, order, helpers.to_product_params(M, po), pos, np.zeros(n_total), st, M.ACTUATOR_CMD, cmd, M.ARITH_LITERAL,
+    vs = VirtualShards(M, world, order, helpers.to_product_params(M, po), pos, np.zeros(n_total), st, M.ACTUATOR_CMD, cmd, M.ARITH_FAST if fast else M.ARITH_LITERAL,
                        M.EXCHANGE_EXPORT_SETS, rendezvous=rendezvous)
     if chaos:
         for r, (g, _) in enumerate(vs.shards):
@@ -59,9 +62,9 @@ for seed in range(first, first + runs):
         done += n
         a, so = vs.gather(), o.get_state()
         assert np.array_equal(a["crashed"], o.has_crashed()), f"seed {seed}: crash flags after {done} ticks"
-        helpers.assert_close(a["f"], o.get_external_force(), 1e-11, f"seed {seed}: forces after {done} ticks")
+        helpers.assert_close(a["f"], o.get_external_force(), rtol_force, f"seed {seed}: forces after {done} ticks")
         for key in ("x", "v", "R", "omega", "motor_rpm"):
-            helpers.assert_close(a[key], so[key], RTOL_LITERAL, f"seed {seed}: {key} after {done} ticks")
+            helpers.assert_close(a[key], so[key], rtol_state, f"seed {seed}: {key} after {done} ticks")
     info, split = vs.info(), [g.split_stats()[0] for g, _ in vs.shards]
     vs.close()
     print(f"seed {seed}: world {world}, {n_total} UAVs, {'slabs' if slabs else 'index shards'}, speed {speed:.1f}, chaos {chaos} us, "
