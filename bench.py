@@ -10,9 +10,10 @@ sub-record: BASELINE configs[4], 1 000 000 UAVs with mutual collisions sharded o
 Rank 0 prints ONE JSON line.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, repeated until 50 ms
-have been measured.  `ms_per_step` / `value` = the median region's DEVICE time (hipEvents on the swarm's streams: before the first
-launch, after the last launch of each stream; MAX over ranks): one region of the driver's K = 20 lasts 0.2 ms, a fifth of it host start-up and synchronize latency, which
-is not throughput.  The wall-clock figure of the same regions is in the line too (`wall_ms_per_step`, `value_wall_clock`).
+have been measured.  `ms_per_step` / `value` = the median region by the WALL clock (time.perf_counter() between the two brackets,
+MAX over ranks) — SURVEY §8d's definition; one region of the driver's K = 20 lasts 0.2 ms, a fifth of it host start-up and synchronize
+latency, and that is included.  The DEVICE time of the same regions (hipEvents on the swarm's streams: before the first launch, after
+the last launch of each stream) is in the line too (`device_ms_per_step`, `value_device_time`) and is what `roofline` is computed from.
 """
 import argparse
 import json
@@ -36,15 +37,25 @@ INFINITY_CACHE_GBS = 8600.0  # lower bound the same guide measured for reads ser
 STATE_BYTES_PER_UAV = 86 * 8 + 4  # swarm_layout.h: F_COUNT doubles + the flag word
 HBM_STREAMING_UAVS = 4_000_000    # 2.8 GB of state, 1.65 GB moved per step: nothing is read twice out of a cache
 
-# algorithmic bytes per UAV-step: one read + one write of everything the step must touch, FP64
-BYTES_PER_UAV_STEP = {
-    "actuator": (25 + 3 + 4 + 1) * 8 + 4 + (25 + 3) * 8,            # 492 B  (n_motors = 4)
-    "position": (25 + 3 + 1 + 24 + 4) * 8 + 4 + (25 + 3 + 24) * 8,  # 876 B
-}
+# algorithmic bytes per UAV-step: one read + one write of everything the step must touch, FP64; n = n_motors
+def bytes_per_uav_step(key, n_motors=4):
+    n = n_motors
+    if key == "actuator":  # read state 21+n, F_ext 3, cmd n, init_z 1 (+ flags); write state 21+n, imu 3
+        return (21 + n + 3 + n + 1) * 8 + 4 + (21 + n + 3) * 8          # 492 B at n = 4
+    return (21 + n + 3 + 1 + 24 + 4) * 8 + 4 + (21 + n + 3 + 24) * 8      # position cascade: 876 B at n = 4, 908 B at n = 6
+
+
 # what the kernels really move per UAV-step: the v_prev, F_ext (while no force was ever applied) and init_z columns are elided
-# (DESIGN §4): read x v R w (18) + cmd 4 + rpm 4 + flags, write x v R w + imu 3 + rpm 4 — and the 24 PID doubles both ways
-BYTES_MOVED_PER_UAV_STEP = {"actuator": (18 + 4 + 4) * 8 + 4 + (18 + 3 + 4) * 8,                # 412 B (PMC: 417)
-                            "position": (18 + 4 + 4 + 24) * 8 + 4 + (18 + 3 + 4 + 24) * 8}      # 796 B
+# (DESIGN §4): read x v R w (18) + cmd + rpm n + flags, write x v R w + imu 3 + rpm n — and the 24 PID doubles both ways
+def bytes_moved_per_uav_step(key, n_motors=4):
+    n = n_motors
+    if key == "actuator":
+        return (18 + n + n) * 8 + 4 + (18 + 3 + n) * 8                     # 412 B at n = 4 (PMC: 417)
+    return (18 + 4 + n + 24) * 8 + 4 + (18 + 3 + n + 24) * 8              # 796 B at n = 4
+
+
+BYTES_PER_UAV_STEP = {k: bytes_per_uav_step(k) for k in ("actuator", "position")}
+BYTES_MOVED_PER_UAV_STEP = {k: bytes_moved_per_uav_step(k) for k in ("actuator", "position")}
 # collision pass: a list tick reads the list head + count and writes the force for every UAV, and gathers the
 # positions of the listed partners of the p UAVs that have any; a search tick is the SURVEY figure
 COLLISION_BYTES = {"list_tick_per_uav": 28, "list_tick_per_uav_with_partner": 150, "search_tick_per_uav": 92, "search_tick_per_candidate": 24}
@@ -58,7 +69,7 @@ def pmc_traffic(args, n, workload=None):
     size = f"{n // 1000}k" if n < 1_000_000 else f"{n // 1_000_000}M"
     if stem is None or args.substeps != 1:
         return None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}_{size}_{args.arith}_summary.json")
         if not os.path.exists(path):
             continue
@@ -159,36 +170,56 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def make_inputs(n, workload, seed, volume_per_uav=64.0):
+def make_inputs(n, workload, seed, volume_per_uav=64.0, n_motors=4):
     from mrs_multirotor_simulator_amd import synthetic  # numpy only: the GPU legs of the bench never touch oracle/ or tests/
     rng = np.random.default_rng(seed)
+    if workload == "config2":
+        # BASELINE configs[1]: the tmux/standalone_400_uavs spawn grid — 20 x 20, 4 m pitch, z = 0, heading 0 — and the
+        # goals of its goto.py: x, y ~ U(-40, 40), z ~ U(2, 20), heading ~ U(-3.14, 3.14), default_rng(400)
+        rng = np.random.default_rng(400)
+        side = int(round(n ** 0.5))
+        assert side * side == n, "config 2 is a square grid"
+        gx, gy = np.meshgrid(np.arange(side) * 4.0, np.arange(side) * 4.0, indexing="ij")
+        st = {"x": np.stack([gx.ravel(), gy.ravel(), np.zeros(n)], axis=1), "heading": np.zeros(n)}
+        cmd = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(2, 20, (n, 1)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
+        return st, cmd
     if workload == "actuator":
-        st = synthetic.random_state(rng, n, 4)
-        cmd = rng.uniform(0.35, 0.60, (n, 4))
+        st = synthetic.random_state(rng, n, n_motors)
+        cmd = rng.uniform(0.35, 0.60, (n, n_motors))
     else:
         side = (volume_per_uav * n) ** (1.0 / 3.0)  # 64 m^3 per UAV by default (BASELINE config 4)
-        st = synthetic.random_state(rng, n, 4, tilted=True)
+        st = synthetic.random_state(rng, n, n_motors, tilted=True)
         st["x"] = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
         cmd = np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
     return st, cmd
 
 
-def cpu_baseline(args, st, cmd):
+def cpu_baseline(args, st, cmd, workload=None, uavs=None, airframe="x500", seconds=None):
     """The oracle (scalar C restatement of the reference, 1 thread like the reference's serial loop) timed on a bounded
     sample of the same workload, built for this host with the flags SURVEY §8d names."""
     from oracle import oracle_swarm as O
-    flags = O.use_native()  # -O3 -march=native -ffp-contract=off, compiled on this machine (falls back to the portable -O2 build)
+    if O._lib is None:
+        flags = O.use_native()  # -O3 -march=native -ffp-contract=off, compiled on this machine (falls back to the portable -O2 build)
+        cpu_baseline.flags = flags
+    flags = getattr(cpu_baseline, "flags", O.PORTABLE_FLAGS)
     import helpers
-    n = min(args.uavs, 20_000)
+    workload = args.workload if workload is None else workload
+    seconds = args.cpu_seconds if seconds is None else seconds
+    n = min(args.uavs if uavs is None else uavs, 20_000)
     o = O.OracleSwarm(n)
-    po = helpers.oracle_params("x500", ground_enabled=True)
-    o.construct(0, n, po)
+    po = helpers.oracle_params(airframe, ground_enabled=True)
+    if workload == "config2":
+        o.construct(0, n, po, st["x"][:n], st["heading"][:n])
+    else:
+        o.construct(0, n, po)
     for nm in ("set_mixer_params", "set_rate_params", "set_attitude_params", "set_velocity_params", "set_position_params"):
         getattr(o, nm)(0, n)
-    o.set_state(0, n, st["x"][:n], st["v"][:n], st["R"][:n], st["omega"][:n], st["motor_rpm"][:n])
-    o.set_input(0, n, O.ACTUATOR_CMD if args.workload == "actuator" else O.POSITION_CMD, cmd[:n])
-    coll = args.workload.endswith("collisions")
+    if workload != "config2":
+        o.set_state(0, n, st["x"][:n], st["v"][:n], st["R"][:n], st["omega"][:n], st["motor_rpm"][:n])
+    o.set_input(0, n, O.ACTUATOR_CMD if workload == "actuator" else O.POSITION_CMD, cmd[:n])
+    coll = workload.endswith("collisions")
     o.step_n(DT, 2)
+    chunk = 5 if n >= 2000 else 500
     steps, t0 = 0, time.perf_counter()
     while True:
         if coll:
@@ -196,13 +227,13 @@ def cpu_baseline(args, st, cmd):
             o.handle_collisions(True, False, 100.0)
             steps += 1
         else:
-            o.step_n(DT, 5)
-            steps += 5
+            o.step_n(DT, chunk)
+            steps += chunk
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds:
+        if el > seconds:
             break
     out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port", "compiler_flags": "gcc " + flags,
-           "sample": f"{n} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c ({flags}), 1 thread "
+           "sample": f"{n} {airframe} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c ({flags}), 1 thread "
                      "(the reference's loop is serial, src/multirotor_simulator.cpp:211-213)"}
     if coll and O.ref_lib() is not None:
         # the reference's OWN broadphase on the same positions: nanoflann build + one radius search per UAV
@@ -213,12 +244,15 @@ def cpu_baseline(args, st, cmd):
         while time.perf_counter() - t0 < 2.0:
             O.ref_lib().ref_nf_build_and_count(pts.ctypes.data_as(C.POINTER(C.c_double)), n, 3.0, 10)
             reps += 1
-        out["collision_broadphase_reference"] = {"kind": "reference", "ms_per_tick": (time.perf_counter() - t0) / reps * 1e3,
-                                                 "sample": f"nanoflann kd-tree build + {n} radius searches, 1 thread"}
-    if not coll:  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out["collision_broadphase_reference"] = {"kind": "reference", "ms_per_tick": ms, "uavs": n, "us_per_uav_tick": ms * 1e3 / n,
+                                                 "sample": f"the reference's nanoflann kd-tree (oracle/_ref, compiled from the reference tree): "
+                                                           f"build + {n} radius searches, 1 thread — what handleCollisions does every tick "
+                                                           "(src/multirotor_simulator.cpp:303-326)"}
+    if not coll and workload != "config2":  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
         cores = os.cpu_count() or 1
         k, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < max(3.0, args.cpu_seconds / 3):
+        while time.perf_counter() - t0 < max(3.0, seconds / 3):
             o.step_n(DT, 10, cores)
             k += 10
         out["all_cores"] = {"value": n * k / (time.perf_counter() - t0), "cores": cores}
@@ -303,15 +337,38 @@ def kernel_name_of(n, workload, arith, substeps):
     return name + "_" + arith
 
 
-def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"), min_ms=None, seed=3):
-    """One timed workload on this rank's GPU: `n` x500 UAVs, regions of exactly `steps` steps (ticks).  Returns (record, st, cmd);
-    the record is built on rank 0 only."""
+def mean_search_candidates(x, inv_cell):
+    """k-bar of SURVEY §8d's collision formula, MEASURED on the positions of the run: per UAV, the other UAVs in the 27 cells around
+    its own — the records a search fetches (the tag filter of collide.hip k_query admits exactly the members of the probed cells)."""
+    c = np.floor(np.asarray(x) * inv_cell).astype(np.int64) + (1 << 20)
+    key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+    uniq, cnt = np.unique(key, return_counts=True)
+    total = np.zeros(len(key))
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                k2 = key + ((dx << 42) + (dy << 21) + dz)
+                at = np.searchsorted(uniq, k2)
+                at[at >= len(uniq)] = len(uniq) - 1
+                total += np.where(uniq[at] == k2, cnt[at], 0)
+    return float(total.mean() - 1.0)  # (minus the UAV itself)
+
+
+def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"), min_ms=None, seed=3, airframe="x500", arith=None):
+    """One timed workload on this rank's GPU: `n` UAVs of one airframe, regions of exactly `steps` steps (ticks).  Returns (record, st,
+    cmd); the record is built on rank 0 only."""
     import mrs_multirotor_simulator_amd as M
+    from mrs_multirotor_simulator_amd import airframes
     torch = R.torch
-    st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav)
-    sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
-    sw.construct(0, n, M.model_params("x500", ground_enabled=True))
-    sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    arith = args.arith if arith is None else arith
+    n_motors = airframes.AIRFRAMES[airframe]["n_motors"]
+    st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav, n_motors=n_motors)
+    sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if arith == "fast" else M.ARITH_LITERAL)
+    if workload == "config2":
+        sw.construct(0, n, M.model_params(airframe, ground_enabled=True), st["x"], st["heading"])
+    else:
+        sw.construct(0, n, M.model_params(airframe, ground_enabled=True))
+        sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
     sw.set_input(0, n, M.ACTUATOR_CMD if workload == "actuator" else M.POSITION_CMD, cmd)
     coll = workload.endswith("collisions")
 
@@ -333,13 +390,14 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
     sw.set_profiling(1)  # one hipEvent pair around every step_n / tick_n call, on the swarm's stream
     times, ev = timed_regions(R, run, sync_local, steps, warmup, args.min_measure_ms if min_ms is None else min_ms, after_region=sw.last_step_kernel_ms)
     sw.set_profiling(0)
-    assert np.all(np.isfinite(sw.get_state(0, 64)["x"]))
+    x_end = sw.get_state(0, n)["x"] if coll else sw.get_state(0, 64)["x"]
+    assert np.all(np.isfinite(x_end[:64]))
     kern_ms = float(np.median([e[0] for e in ev]))
     n_launch = ev[0][1]
-    # `value` comes from the DEVICE time of the K-step region (hipEvents on the swarm's stream, recorded right before the first and
-    # right after the last launch; MAX over ranks, median over regions): at the driver's K = 20 a region lasts 0.2 ms and the
-    # wall clock around it is one fifth host start-up + synchronize latency, which is not throughput.  The wall-clock figure of the
-    # same regions is reported next to it (wall_ms_per_step).
+    # `value` is the contract's figure: UAVs x steps / WALL seconds of regions of exactly K steps, each bracketed by
+    # barrier + synchronize on both sides, MAX over ranks, median over the regions — host start-up and synchronize latency of the
+    # region included (at the driver's K = 20 a region lasts 0.2 ms, about a fifth of it that latency).  The device time of the
+    # same regions (hipEvents on the swarm's streams) is reported next to it and is what the roofline is computed from.
     wall = float(np.median(times))
     el = R.max_over_ranks(kern_ms * n_launch * 1e-3)
     out = None
@@ -347,16 +405,17 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
         world = R.world
         key = "actuator" if workload == "actuator" else "position"
         # one launch reads and writes the state once, however many sub-steps it fuses: no roofline credit for fusion
-        alg_bytes = BYTES_PER_UAV_STEP[key] * n
+        b_alg, b_mov = bytes_per_uav_step(key, n_motors), bytes_moved_per_uav_step(key, n_motors)
+        alg_bytes = b_alg * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        moved = BYTES_MOVED_PER_UAV_STEP[key] * n / (kern_ms * 1e-3) / 1e9
+        moved = b_mov * n / (kern_ms * 1e-3) / 1e9
         tr, tr_src = traffic  # measured by main() before this process touched the GPU; (None, why) otherwise
-        if tr is None and args.traffic != "off":
-            if args.traffic == "live" and world == 1:
+        if tr is None and args.traffic != "off" and airframe == "x500" and arith == args.arith:
+            if args.traffic == "live" and world == 1 and traffic[1] != "not requested":
                 sys.stderr.write(f"bench.py: live PMC traffic unavailable for {n} UAVs / {workload} ({tr_src}); using the committed profile\n")
             tr, tr_src = pmc_traffic(args, n, workload)
         npad = (n + 63) // 64 * 64
-        kernel_name = kernel_name_of(n, workload, args.arith, args.substeps)
+        kernel_name = kernel_name_of(n, workload, arith, args.substeps)
         # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1
         if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-steps // args.substeps) >= 4:
@@ -365,21 +424,26 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
             tr *= launches_per_step  # the PMC figure is per dispatch; `achieved` and `traffic` are both per step
         touched = STATE_BYTES_PER_UAV * n
         resident = touched < INFINITY_CACHE_BYTES
+        if workload == "actuator":
+            wl = f"BASELINE configs[2]: {n} {airframe} UAVs per GPU, {workload} references, dt=1 ms, RK4, ground on"
+        elif workload == "config2":
+            wl = (f"BASELINE configs[1]: {n} {airframe} hexarotors (tmux/standalone_400_uavs: 20 x 20 grid, 4 m pitch), position references "
+                  "(goto.py goals), no collisions, dt=1 ms")
+        elif coll:
+            wl = f"BASELINE configs[3]: {n} {airframe} UAVs, position references + mutual collisions + ground plane, {args.volume_per_uav:g} m^3 per UAV, dt=1 ms"
+        else:
+            wl = f"{n} {airframe} UAVs per GPU, {workload}, dt=1 ms"
         out = {
-            "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * steps / el, "unit": "UAV-steps/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "metric": "UAV-steps/sec (whole node) at 1000 Hz sim-dt", "value": world * n * steps / wall, "unit": "UAV-steps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "regions": len(times), "wall_ms_per_step": wall / steps * 1e3, "first_region_wall_ms_per_step": times[0] / steps * 1e3,
-            "value_wall_clock": world * n * steps / wall,
-            "timing": f"{len(times)} regions of exactly {steps} steps, each bracketed by barrier + synchronize; ms_per_step / value = median region's "
-                      "device time (hipEvent pair around the region's launches), MAX over ranks; wall_ms_per_step / value_wall_clock = the same "
-                      "regions by time.perf_counter() (host start-up and synchronize latency included)",
-            "config": {"workload": f"BASELINE configs[2]: {n} x500 UAVs per GPU, {workload} references, dt=1 ms, RK4, ground on"
-                       if workload == "actuator" else
-                       (f"BASELINE configs[3]: {n} x500 UAVs, position references + mutual collisions + ground plane, {args.volume_per_uav:g} m^3 per UAV, dt=1 ms"
-                        if coll else f"{n} x500 UAVs per GPU, {workload}, dt=1 ms"),
-                       "uavs_per_gpu": n, "arith": args.arith, "substeps_per_launch": args.substeps,
-                       "parallelism": f"{world} independent shard(s), no collective on the data path"},
+            "regions": len(times), "device_ms_per_step": el / steps * 1e3, "value_device_time": world * n * steps / el,
+            "first_region_wall_ms_per_step": times[0] / steps * 1e3,
+            "timing": f"{len(times)} regions of exactly {steps} steps, each bracketed by barrier + synchronize on both sides; ms_per_step / value = "
+                      "median region by time.perf_counter() (wall clock: host start-up and synchronize latency of the region included), MAX over "
+                      "ranks; device_ms_per_step / value_device_time = the same regions by a hipEvent pair around the region's launches",
+            "config": {"workload": wl, "uavs_per_gpu": n, "airframe": airframe, "n_motors": n_motors, "arith": arith,
+                       "substeps_per_launch": args.substeps, "parallelism": f"{world} independent shard(s), no collective on the data path"},
             # `peak` is the HBM3E spec figure in every regime (comparable across sizes); while the touched state fits the 256 MiB Infinity
             # Cache the operative limit is that cache, not HBM: `bound` says so, and the guide's measured lower bound for it is given
             "roofline": {"bound": "infinity-cache" if resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -388,13 +452,13 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                          "peak_by_regime": {"hbm-streaming": HBM_PEAK_GBS, "infinity-cache-resident": INFINITY_CACHE_GBS},
                          "frac_of_regime_peak": achieved / (INFINITY_CACHE_GBS if resident else HBM_PEAK_GBS),
                          "touched_bytes": touched,
-                         "bytes_moved_per_uav_step": BYTES_MOVED_PER_UAV_STEP[key], "moved_GBps": moved,
+                         "bytes_moved_per_uav_step": b_mov, "moved_GBps": moved,
                          "frac_moved_of_peak": moved / HBM_PEAK_GBS,
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": moved / HBM_ACHIEVABLE_GBS,
                          "kernel": kernel_name if not coll
                          else "whole tick: " + kernel_name + " + neighbour search every ~27 ticks (time per tick, bytes of the step only)",
                          "kernel_avg_ms": kern_ms, "launches": n_launch,
-                         "algorithmic_bytes_per_uav_step": BYTES_PER_UAV_STEP[key],
+                         "algorithmic_bytes_per_uav_step": b_alg,
                          "concurrent_launches_per_step": launches_per_step,
                          "method": "hipEvents around each timed region: one before the first launch, one per stream after its last launch (the later "
                                    "of the two ends the region; joining the streams afterwards is bookkeeping): elapsed / steps, inter-launch gaps "
@@ -413,18 +477,29 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
             out["config"]["launches_replayed"], out["config"]["searches_queued_ahead"] = int(replayed), int(ahead)
             p = 0.06  # fraction of UAVs with a listed partner at 64 m^3 per UAV
             cb = COLLISION_BYTES["list_tick_per_uav"] + COLLISION_BYTES["list_tick_per_uav_with_partner"] * p
+            # the search itself (92 + 24 k-bar bytes per UAV): k-bar measured on the positions at the end of the run (list
+            # cells of collide.hip: edge sqrt(3) + skin + 0.018 m), the two search kernels timed live, back to back, by hipEvents
+            kbar = mean_search_candidates(x_end, 1.0 / (3.0 ** 0.5 + 0.5 + 0.0179491924))
+            search_ms = sw.debug_search_ms(reps=16)
+            search_bytes = (COLLISION_BYTES["search_tick_per_uav"] + COLLISION_BYTES["search_tick_per_candidate"] * kbar) * n
             out["roofline_collision"] = {
                 "bound": "infinity-cache" if resident else "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                "algorithmic_bytes_per_uav_list_tick": cb, "algorithmic_bytes_per_uav_search_tick": "92 + 24 * candidates",
-                "achieved_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9,
-                "frac_whole_tick": (BYTES_PER_UAV_STEP[key] + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_uav_list_tick": cb,
+                "algorithmic_bytes_per_uav_search_tick": COLLISION_BYTES["search_tick_per_uav"] + COLLISION_BYTES["search_tick_per_candidate"] * kbar,
+                "search_candidates_per_uav": kbar, "search_bytes": search_bytes, "search_ms": search_ms,
+                "search_kernels": "k_pack_insert<1> + k_query<1> (collide.hip), 16 searches back to back between two hipEvents",
+                "search_achieved": search_bytes / (search_ms * 1e-3) / 1e9, "search_frac": search_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ticks_per_search": (int(ticks) / max(1, int(searches))),
+                "achieved_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9,
+                "frac_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "whole tick = fused step + collision launch, plus the neighbour search amortised over the ticks between two searches, over "
-                        "(step bytes + list-tick bytes); per-kernel times: profiles/r03_collision_tick_*"}
+                        "(step bytes + list-tick bytes); search_* = one search on its own against SURVEY 8d's (92 + 24 k) B per UAV; per-kernel "
+                        "times: profiles/r04_collision_tick_*"}
     del sw
     return out, st, cmd
 
 
-SUB_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "regions", "wall_ms_per_step", "value_wall_clock", "config", "roofline", "roofline_collision")
+SUB_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "regions", "device_ms_per_step", "value_device_time", "config", "roofline", "roofline_collision", "cpu_baseline")
 
 
 def sub_record(rec):
@@ -587,8 +662,19 @@ def main():
         # config 4 (collisions + ground) in the form tick_n runs it — fused step + collision launches, searches queued ahead
         rec, _, _ = step_leg(args, R, HBM_STREAMING_UAVS, "actuator", 200, 50, traffic=live.get((HBM_STREAMING_UAVS, "actuator"), no_traffic), min_ms=150.0)
         out["hbm_streaming"] = sub_record(rec)
-        rec, _, _ = step_leg(args, R, 100_000, "position+collisions", 300, 100, traffic=live.get((100_000, "position+collisions"), no_traffic), min_ms=30.0)
+        rec, st4, cmd4 = step_leg(args, R, 100_000, "position+collisions", 300, 100, traffic=live.get((100_000, "position+collisions"), no_traffic), min_ms=30.0)
+        if R.rank == 0 and not args.no_cpu_baseline:  # incl. the one CPU number that is the reference's OWN code: its nanoflann broadphase
+            rec["cpu_baseline"] = cpu_baseline(args, st4, cmd4, workload="position+collisions", uavs=100_000, seconds=min(args.cpu_seconds, 8.0))
+        del st4, cmd4
         out["config4"] = sub_record(rec)
+        # the bit-faithful flavour (reference operation order, no FMA contraction) on the headline workload
+        rec, _, _ = step_leg(args, R, 100_000, "actuator", 300, 50, min_ms=30.0, arith="literal")
+        out["literal"] = sub_record(rec)
+        # BASELINE configs[1]: 400 f550 hexarotors, position cascade, no collisions (launch-bound: one wave per seven SIMDs)
+        rec, st2, cmd2 = step_leg(args, R, 400, "config2", 2000, 200, min_ms=30.0, airframe="f550")
+        if R.rank == 0 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args, st2, cmd2, workload="config2", uavs=400, airframe="f550", seconds=min(args.cpu_seconds, 4.0))
+        out["config2"] = sub_record(rec)
         out["sharded_rank_standin"] = sharded_rank_record(args)
 
     import threading

@@ -351,6 +351,12 @@ enum {
 int mrs_swarm_debug_component(mrs_swarm_t* s, int32_t component, int32_t first, int32_t count, const double* in, int32_t in_stride, double* out,
                               int32_t out_stride, double dt);
 
+/* measurement hook: average device time (ms) of ONE neighbour search of the single-GPU collision pass (pack + insert, then the
+ * list-building query — what replaces nanoflann's per-tick kd-tree build + radius searches, src/multirotor_simulator.cpp:303-326),
+ * `reps` searches back to back between two hipEvents on the swarm's stream.  Latches the forces / crash flags of
+ * handleCollisions(true, crash, rebounce) on the current positions. */
+int mrs_swarm_debug_search_ms(mrs_swarm_t* s, int32_t reps, int32_t crash, double rebounce, double* avg_ms);
+
 /* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
  * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
  * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */

@@ -1103,7 +1103,7 @@ __global__ void k_class_list(int n_blocks, const uint32_t* blk_class, uint32_t* 
 }
 
 // interior blocks that list a UAV of a boundary block (translated lists: a local entry is the UAV's index)
-__global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* blk_class) {
+__global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* blk_class, uint32_t* fctl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || (blk_class[i >> 6] & MRS_BLK_BOUNDARY)) return;
   const uint32_t cnt = nbr_cnt[i];
@@ -1112,7 +1112,11 @@ __global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_c
     const uint32_t e = nbr[(size_t)k * (size_t)n + (size_t)i];
     if (!(e & MRS_NBR_FOREIGN) && (blk_class[e >> 6] & MRS_BLK_BOUNDARY)) l1 = true;
   }
-  if (l1) atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1);
+  if (l1 && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
+}
+// the layer-1 block count where the host reads it without a synchronisation of its own (it looks after the serial ticks that follow a search)
+__global__ void k_layer1_to_host(const uint32_t* fctl, volatile uint32_t* hostw) {
+  __hip_atomic_store(&hostw[CTL_NL1], fctl[CTL_NL1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet
@@ -1191,18 +1195,20 @@ __global__ void k_list_eval_cd(SwarmDev sw, CollDev cd) {
 // the stall words of all ranks (headers of the gathered export buffer) folded into this rank's control words: run at the end of a
 // batch of ticks, whose last launch nobody has looked behind yet
 // progress_tau != 0: also stands in for the fused launch of a rank that holds no UAVs (it reports progress and the warning word)
-__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_send, const uint32_t* fctl, volatile uint32_t* hostw, uint32_t progress_tau) {
+__global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_send, uint32_t* fctl, volatile uint32_t* hostw, uint32_t progress_tau) {
   uint32_t* own   = (uint32_t*)x_send;  // the rank's own header words (MRS_HDR_*): what it knows, what its next collective carries
-  uint32_t  stall = own[MRS_HDR_STALL], warn = own[MRS_HDR_WARN];
+  uint32_t  stall = own[MRS_HDR_STALL], warn = own[MRS_HDR_WARN], herr = 0u;
   // (a communicator of ONE rank: the launches keep their words where a single GPU keeps them)
   if (fctl[CTL_STALL] != 0u && (stall == 0u || fctl[CTL_STALL] < stall)) stall = fctl[CTL_STALL];
   if (fctl[CTL_WARN] != 0u && (warn == 0u || fctl[CTL_WARN] < warn)) warn = fctl[CTL_WARN];
   for (int q = 0; q < world; q++) {
     const uint32_t* hq = (const uint32_t*)(x_recv + (size_t)q * (size_t)block);
     const uint32_t  h = hq[MRS_HDR_STALL], wq = hq[MRS_HDR_WARN];
+    herr |= hq[MRS_HDR_ERROR];
     if (h != 0u && (stall == 0u || h < stall)) stall = h;
     if (wq != 0u && (warn == 0u || wq < warn)) warn = wq;
   }
+  if ((herr & 3u) != 0u) fctl[CTL_ERROR] |= (herr & 3u) << 8;  // some rank's kernels reported an error: every rank's call fails
   own[MRS_HDR_STALL] = stall;
   own[MRS_HDR_WARN]  = warn;
   __hip_atomic_store(&hostw[CTL_STALL], stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1435,6 +1441,7 @@ extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long 
   hipLaunchKernelGGL(k_search_reset, dim3((unsigned)((n_max + 2 + 255) / 256)), dim3(256), 0, st, w->fctl, map_send, n_max + 2, w->blk_class,
                      (sw.n + 63) / 64);
   w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
+  w->hostw[CTL_NL1] = 0xFFFFFFFFu;  // "not known yet": k_layer1_to_host writes the count at the end of the search
   if (sw.n > 0) {
     const int n_blocks = (sw.n + 63) / 64;
     hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl,
@@ -1452,7 +1459,8 @@ extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, 
   if (sw.n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, n_max + 2, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
                      maps, rec_all, w->x_recv, w->x_const, w->fctl);
-  hipLaunchKernelGGL(k_class_layer1, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, w->nbr, w->nbr_cnt, w->blk_class);
+  hipLaunchKernelGGL(k_class_layer1, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, w->nbr, w->nbr_cnt, w->blk_class, w->fctl);
+  hipLaunchKernelGGL(k_layer1_to_host, dim3(1), dim3(1), 0, st, w->fctl, w->hostw);
   return hipGetLastError();
 }
 
@@ -1486,15 +1494,16 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->blk_list  = w->blk_list;
   cd->epoch     = w->epoch;
   cd->pred_lim  = 0.5 * SKIN2 * (1.0 - 1e-9);
-  cd->pred_hdt  = INFINITY;  // (the caller sets horizon * dt: mrs_collide_export_part)
+  cd->pred_hdt  = -1.0;  // (nothing announced unless the caller says so: mrs_collide_export_part)
   return hipSuccess;
 }
 
 // the part of a split tick this launch is (MRS_PART_*) and the step of the displacement bound
-extern "C" void mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int bound_ok) {
+// announce: the protocol runs split ticks (on any rank), so "may leave its skin within MRS_PRED_HORIZON steps" has to be reported ahead
+extern "C" void mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int announce) {
   cd->part          = part;
   cd->n_bnd         = n_bnd;
-  cd->pred_hdt      = bound_ok ? (double)MRS_PRED_HORIZON * dt : INFINITY;
+  cd->pred_hdt      = announce ? (double)MRS_PRED_HORIZON * dt : -1.0;
 }
 
 // a run of split ticks starts behind launch `tau` (everything before it has completed in stream order)

@@ -65,7 +65,7 @@ extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t 
 extern "C" void mrs_collide_free(CollideWork* w);
 extern "C" hipError_t mrs_launch_step_coll_literal(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
 extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double dt, int variant, int grid_blocks, hipStream_t st);
-extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int bound_ok);
+extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int announce);
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
 extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st);
@@ -226,8 +226,10 @@ static void derive_type(const TypeKey& k, double dt, TypeParams& t) {
   t.vel_kp = k.vel.kp; t.vel_kd = k.vel.kd; t.vel_ki = k.vel.ki; t.vel_sat = k.vel.max_acceleration;
   t.att_kp = k.att.kp; t.att_kd = k.att.kd; t.att_ki = k.att.ki;
   t.att_sat_rp = k.att.max_rate_roll_pitch; t.att_sat_yaw = k.att.max_rate_yaw;
-  {  // displacement bound (swarm_layout.h): thrust <= sum_m |alloc[3][m]| max(rpm_m, max_rpm)^2 <= |thrust now| + cap, times 1.5 for the
-     // re-orthonormalised body z of a not quite orthonormal R
+  {  // displacement bound (swarm_layout.h): thrust <= sum_m alloc[3][m] max(rpm_m, max_rpm)^2 <= |thrust now| + cap (pred_thr is the
+     // factor of the first term, evaluated by the kernel from the motor speeds it has — also speeds the host set beyond max_rpm, or
+     // a max_rpm lowered through set_params under running motors), times 1.5 for the re-orthonormalised body z of a not quite
+     // orthonormal R
     double cap = 0.0;
     bool   ok  = p.mass > 0 && p.max_rpm >= 0;
     for (int m = 0; m < p.n_motors; m++) {
@@ -354,7 +356,7 @@ struct mrs_swarm {
   double    split_max_fraction = 0.25;  // ... and MRS_SHARD_SPLIT_MAX_FRACTION: the boundary launch may cover at most this share of the blocks
   uint32_t  x_nbnd = 0;             // boundary blocks of this rank as of the last search
   double    x_dt = -1.0;            // dt of the previous call: the announcements of its last launches assumed it
-  bool      rpm_over = false;       // some motor speed was set beyond its airframe's max_rpm: the displacement bound does not hold
+  int       resident_waves = 2048;  // wave slots of the device at the interior kernel's occupancy (2 per SIMD): see split_ok()
   int64_t   x_split_ticks = 0;
   // test hook (mrs_swarm_debug_chaos): this rank's host sleeps a random time before every launch of a sharded tick and, half of
   // the time, decides on the stall / warning words as it read them one launch earlier (still within what the protocol guarantees)
@@ -765,6 +767,11 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
     HIPCHK(hipExtStreamCreateWithCUMask(&s->stream_i, (uint32_t)words, mi.data()));
   }
   HIPCHK(hipEventCreate(&s->ev_end2));
+  {
+    int ncu = 0;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id));
+    if (ncu > 0) s->resident_waves = ncu * 4 * 2;
+  }
   if (const char* e = getenv("MRS_SPLIT_STREAMS")) s->split_steps = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
@@ -1195,8 +1202,12 @@ static int wait_for_progress(mrs_swarm* s, const volatile unsigned* hw, unsigned
   for (unsigned long spins = 1; behind(); spins++) {
     __builtin_ia32_pause();
     if ((spins & 0xFFFFul) != 0) continue;
-    const hipError_t q = hipStreamQuery(s->stream);  // a launch that failed asynchronously never writes its words
-    if (q != hipSuccess && q != hipErrorNotReady) return fail(MRS_ERR_HIP, std::string("fused launches: ") + hipGetErrorString(q));
+    // a launch that failed asynchronously never writes its words — on whichever stream of a split tick it ran
+    for (hipStream_t st : {s->stream, s->stream2, s->stream_i, s->stream_b}) {
+      if (!st) continue;
+      const hipError_t q = hipStreamQuery(st);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(MRS_ERR_HIP, std::string("fused launches: ") + hipGetErrorString(q));
+    }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
       return fail(MRS_ERR_HIP, "the device made no progress for " + std::to_string((int)limit_s) + " s: waiting for launch " + std::to_string(index - (unsigned)lead) +
                                    ", progress word " + std::to_string(hw[CTL_PROGRESS]) + ", stall word " + std::to_string(stall_word(hw)) + ", warning word " +
@@ -1685,6 +1696,8 @@ int comm_setup(mrs_swarm* s, int world, int rank, int64_t n_total) {
   const int64_t base = n_total / world, rem = n_total % world;
   const int64_t mine = base + (rank < rem ? 1 : 0);  // equal-count shards, sizes differ by at most one
   if (mine != s->n) return fail(MRS_ERR_ARG, "this swarm does not hold the shard of its rank (n_total / world UAVs, the first n_total % world ranks one more)");
+  // (the position records of a shard are addressed through a buffer descriptor with 32-bit byte offsets: step_device.inc store_pos_sc1)
+  if ((long long)s->n >= (1ll << 27)) return fail(MRS_ERR_ARG, "a shard of a sharded swarm holds at most 2^27 - 1 UAVs (use more ranks)");
   return MRS_OK;
 }
 
@@ -1765,6 +1778,12 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
   // polled inside a kernel; collective libraries allocate their flag and staging memory the same way).  MRS_PEER_WINDOW_MEMORY =
   // finegrained | coarse for runtimes that cannot export an uncached allocation (every access of the exchange kernel is
   // system-scope either way).
+  struct Release {  // any failure below gives the window, the ticket words and the pinned error word back
+    mrs_swarm* p;
+    ~Release() {
+      if (p) peer_release(p);
+    }
+  } release{s};
   const char* kind = getenv("MRS_PEER_WINDOW_MEMORY");
   if (kind && strcmp(kind, "coarse") == 0)
     HIPCHK(hipMalloc(&s->peer_window, s->peer_window_bytes));
@@ -1780,12 +1799,10 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries IPC handles as 64 bytes");
     hipIpcMemHandle_t h;
     const hipError_t  e = hipIpcGetMemHandle(&h, s->peer_window);
-    if (e != hipSuccess) {
-      peer_release(s);
-      return fail(MRS_ERR_HIP, std::string("peer window: hipIpcGetMemHandle: ") + hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(MRS_ERR_HIP, std::string("peer window: hipIpcGetMemHandle: ") + hipGetErrorString(e));
     memcpy(ipc_handle64, &h, 64);
   }
+  release.p = nullptr;
   if (window) *window = s->peer_window;
   s->peer_world   = world;
   s->peer_rank    = rank;
@@ -2084,7 +2101,7 @@ int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval)
     CollDev  cd;
     SwarmDev v = s->view();
     HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
-    mrs_collide_export_part(&cd, MRS_PART_FULL, 0u, dt, s->rpm_over ? 0 : 1);
+    mrs_collide_export_part(&cd, MRS_PART_FULL, 0u, dt, s->shard_split ? 1 : 0);  // (MRS_SHARD_SPLIT=0: round 2's protocol, nothing announced)
     s->region_launches++;
     const int variant = s->n_cascade > 0 ? 0 : 1;
     if (s->arith == MRS_ARITH_FAST)
@@ -2110,7 +2127,7 @@ int launch_split_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval,
   SwarmDev v = s->view();
   HIPCHK(mrs_collide_export_dev(&v, s->cwork, (int64_t)s->comm_rank * s->comm_n_max, s->tau + 1, eval.on ? 1 : 0, eval.crash, eval.rebounce, &cd));
   s->region_launches++;
-  const int      variant = s->n_cascade > 0 ? 0 : 1, bound_ok = s->rpm_over ? 0 : 1;
+  const int      variant = s->n_cascade > 0 ? 0 : 1, bound_ok = 1;
   const unsigned grid_b  = s->x_nbnd > 0 ? s->x_nbnd : 1u;
   auto launch = [&](const CollDev& c, int grid, hipStream_t st) {
     return s->arith == MRS_ARITH_FAST ? mrs_launch_step_coll_fast(v, c, dt, variant, grid, st) : mrs_launch_step_coll_literal(v, c, dt, variant, grid, st);
@@ -2156,9 +2173,22 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   if (dt != s->x_dt) s->x_ok = false;  // the announcements of the last call's final launches assumed its dt: start from a search
   s->x_dt = dt;
   const int nb = (s->n + 63) / 64;
+  const volatile unsigned* hw = nullptr;  // pinned host mirror of the control words (exists once a search has run)
   auto split_ok = [&]() {
     // (a communicator of one rank has no boundary and announces nothing: its exact reports need the serial form)
-    return protocol_split && s->comm_world > 1 && s->n > 0 && nb >= s->split_min_blocks && (double)s->x_nbnd <= s->split_max_fraction * nb && s->mixed_blocks.empty() && s->stream2 != nullptr;
+    if (!(protocol_split && s->comm_world > 1 && s->n > 0 && nb >= s->split_min_blocks && (double)s->x_nbnd <= s->split_max_fraction * nb && s->mixed_blocks.empty() && s->stream2 != nullptr))
+      return false;
+    // Residency: the waves that SPIN inside a split tick — block 0 and the layer-1 blocks of an interior launch waiting for
+    // the boundary launch of the previous tick, the boundary blocks waiting for an interior launch — hold their wave slots while they
+    // wait.  "Producers are enqueued before consumers" covers the hardware queues, not SIMD and register slots: if spinning interior
+    // waves could fill the device, a boundary launch queued behind a late collective would find no slot and the tick would end in the
+    // 10-s give-up.  So a rank stays in the serial form unless the spinners leave at least half of the wave slots (at the interior
+    // kernel's two waves per SIMD) to everybody else — unless the boundary chain owns compute units of its own (MRS_SPLIT_CU_RESERVE).
+    // The count comes from the search (CTL_NL1, mirrored to the host words by its last launch); unknown yet: serial.
+    const unsigned nl1 = hw ? hw[CTL_NL1] : 0xFFFFFFFFu;
+    if (nl1 == 0xFFFFFFFFu) return false;
+    if (s->cu_reserve > 0) return true;
+    return (long long)nl1 + 1 <= s->resident_waves / 2 && (long long)s->x_nbnd <= s->resident_waves / 4;
   };
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
@@ -2181,7 +2211,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       continue;
     }
     // ---- a segment of fused ticks ----
-    const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+    hw = mrs_collide_host_words(s->cwork);
     if (!hw) return fail(MRS_ERR_HIP, "export-set exchange: the control words of the fused launches do not exist");
     const unsigned first = s->tau + 1;                                 // launch indices run on from the last search
     unsigned       last  = s->tau + (unsigned)(n_ticks - done);       // ... to the end of the call, unless a word says otherwise
@@ -2275,6 +2305,9 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
   if (s->peer_err && *s->peer_err) return peer_failed(s);
   if (w[CTL_ERROR] & 1u) return fail(MRS_ERR_HIP, "split sharded tick: a launch waited in vain for the launch on the other stream (the results of this call are not valid; the stream and the communicator are dead: use a fresh process)");
   if (w[CTL_ERROR] & 2u) return fail(MRS_ERR_HIP, "split sharded tick: a UAV left its skin without the displacement bound announcing it (DESIGN §5) — the results of this call are not valid; run with MRS_SHARD_SPLIT=0 on every rank and report the case");
+  if (w[CTL_ERROR] & 0x300u)  // (any rank's error invalidates every rank's results: the ranks that only HEARD of it would otherwise return MRS_OK with a wrong state)
+    return fail(MRS_ERR_HIP, std::string("sharded tick: another rank of the swarm reported ") + ((w[CTL_ERROR] & 0x200u) ? "an unannounced skin exit (displacement bound violated)" : "a wait that ran out") +
+                                 " — the results of this call are not valid on ANY rank");
   return MRS_OK;
 }
 }  // namespace
@@ -2287,6 +2320,7 @@ int mrs_swarm_tick_sharded_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t
   if (!(dt > 0) || n_ticks < 0) return fail(MRS_ERR_ARG, "bad tick arguments");
   if (n_ticks == 0) return MRS_OK;
   HIPCHK(hipSetDevice(s->device));
+  s->cstream = s->stream;  // (a call that failed inside a split segment may have left it on the boundary chain's stream)
   int rc = upload_types(s, dt);
   if (rc) return rc;
   // Host writes since the last sharded tick (set_state, set_mass, ... possibly on this rank only) do not touch x_ok: all ranks must
@@ -2386,8 +2420,6 @@ int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const doub
           for (int k = 0; k < count; k++) {
             const mrs_model_params_t& mp = s->keys[s->uav_type[(size_t)first + k]].mp;
             s->stage[(size_t)k] = j < mp.n_motors ? it.p[(size_t)k * it.w + j] : 0.0;
-            // (the motor low-pass keeps |rpm| <= max_rpm once it is: the thrust cap of the sharded tick's displacement bound rests on that)
-            if (!(fabs(s->stage[(size_t)k]) <= mp.max_rpm)) s->rpm_over = true;
           }
           if ((rc = put_column(s, it.f + j, first, count, s->stage.data()))) return rc;
         } else if ((rc = put_strided(s, it.f + j, first, count, it.p, it.w, j))) {
@@ -2717,6 +2749,35 @@ int mrs_swarm_debug_collision_words(mrs_swarm_t* s, uint32_t* out8) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(mrs_collide_debug_words(s->cwork, s->stream, out8));
   return MRS_OK;
+}
+
+// measurement hook (bench.py roofline_collision): `reps` neighbour searches of the single-GPU collision pass back to back on the
+// swarm's stream — pack + insert, then the list-building query, exactly what a tick that repeats the search launches — between
+// two hipEvents.  The forces / crash flags latched are those of handleCollisions(enabled, crash, rebounce) on the current positions.
+int mrs_swarm_debug_search_ms(mrs_swarm_t* s, int32_t reps, int32_t crash, double rebounce, double* avg_ms) {
+  MRS_ENTER(s);
+  if (!s || reps < 1 || !avg_ms) return fail(MRS_ERR_ARG, "bad search-timing arguments");
+  if (s->comm_world > 1 || !s->use_lists) return fail(MRS_ERR_ARG, "search timing: single-GPU swarms with neighbour lists only");
+  if (s->n == 0) { *avg_ms = 0.0; return MRS_OK; }
+  HIPCHK(hipSetDevice(s->device));
+  int rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001);
+  if (rc) return rc;
+  const mrs_swarm::Collide c{true, 1, crash, rebounce};
+  if ((rc = collide_now(s, c, /*force=*/true))) return rc;  // buffers exist, tables are in their steady state
+  while (s->ev.size() < 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    s->ev.push_back(e);
+  }
+  HIPCHK(hipEventRecord(s->ev[0], s->stream));
+  for (int k = 0; k < reps; k++) HIPCHK(mrs_collide_run_lists(s->view(), &s->cwork, crash, rebounce, 1, 0u, s->stream));
+  HIPCHK(hipEventRecord(s->ev[1], s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+  *avg_ms = (double)ms / reps;
+  s->fext_active = true;
+  return collide_now(s, c, /*force=*/true);  // host bookkeeping (list completeness, lazies) as after any stand-alone pass
 }
 
 int mrs_swarm_set_profiling(mrs_swarm_t* s, int32_t enabled) {

@@ -64,8 +64,8 @@ struct TypeParams {
   double  rate_kp[3], rate_kd[3], rate_ki[3];              // gains * J(i,i), rate_controller.hpp:56-65
   // displacement bound of the sharded collision tick ("prediction"): |acceleration| over the coming steps is at most
   //   pred_a0 + pred_thr * |allocation*rpm^2 thrust of this step| + (listed partners) * |rebounce| + pred_drag * speed^2
-  double  pred_a0;    // g + 1.5 * (sum_m |alloc[3][m]|) * max_rpm^2 / mass; +inf when the bound cannot be given (a negative thrust column)
-  double  pred_thr;   // 1.5 / mass
+  double  pred_a0;    // g + 1.5 * (sum_m alloc[3][m]) * max_rpm^2 / mass; +inf when the bound cannot be given (a negative thrust column)
+  double  pred_thr;   // 1.5 / mass (times the thrust of the current step: covers motor speeds beyond max_rpm — set by the host, or a lowered max_rpm)
   double  pred_drag;  // |resist_k| / mass
 };
 
@@ -106,6 +106,7 @@ struct Pos4 {
 };
 #define MRS_HDR_STALL 0
 #define MRS_HDR_WARN  1
+#define MRS_HDR_ERROR 2  // the rank's CTL_ERROR bits: every rank's call fails when any rank's kernels reported an error
 struct PartnerConst {
   double mass, arm_length, prop_radius, _pad;
 };
@@ -125,9 +126,11 @@ enum {
   // words of its own — one writer per word at any time; the host takes the smaller non-zero of a pair
   CTL_STALL2 = 6,
   CTL_WARN2 = 7,
-  CTL_ERROR = 8,     // bit 0: a bounded in-kernel wait ran out; bit 1: a UAV left its skin without the displacement bound announcing it
+  CTL_ERROR = 8,     // bit 0: a bounded in-kernel wait ran out; bit 1: a UAV left its skin without the displacement bound announcing it;
+                     // bits 8-9: the same, reported by SOME rank of the sharded swarm (folded from the export headers, MRS_HDR_ERROR)
   CTL_I_STARTED = 9, // tick index of the last interior launch that has started (so the interior launch before it is complete)
   CTL_NBND = 11,     // 64-UAV blocks of this rank that hold a boundary UAV (set by the search)
+  CTL_NL1 = 12,      // interior blocks that list a UAV of a boundary block (MRS_BLK_LAYER1; set by the search, mirrored to the host words)
   CTL_WORDS = 16
 };
 // class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)
@@ -164,6 +167,6 @@ struct CollDev {
   const uint32_t*     blk_list;   // [n_bnd]
   uint32_t*           epoch;      // [blocks]
   uint32_t            n_bnd, _pad3;
-  double              pred_hdt;   // horizon * dt (+inf: the bound cannot be given for this swarm — every tick announces)
+  double              pred_hdt;   // horizon * dt; < 0: nothing is announced (serial protocol, MRS_SHARD_SPLIT=0: every launch tests exactly)
   double              pred_lim;   // sqrt(lim2)
 };

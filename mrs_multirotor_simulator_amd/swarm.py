@@ -99,6 +99,7 @@ ABI_SYMBOLS = [
     "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
+    "mrs_swarm_debug_search_ms",
 ]
 
 _lib = None
@@ -276,6 +277,7 @@ def load_library():
         "mrs_swarm_get_collision_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
+        "mrs_swarm_debug_search_ms": [vp, i32, i32, f64, dp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -436,6 +438,12 @@ class Swarm:
         out = np.zeros((count, wo))
         _check(_lib.mrs_swarm_debug_component(self._h, int(component), int(first), int(count), _dp(rows), wi, _dp(out), wo, float(dt)))
         return out
+
+    def debug_search_ms(self, reps=8, crash=False, rebounce=100.0):
+        """average device time (ms) of one neighbour search (pack + insert, list-building query) — measurement hook of bench.py"""
+        ms = C.c_double()
+        _check(_lib.mrs_swarm_debug_search_ms(self._h, int(reps), int(bool(crash)), float(rebounce), C.byref(ms)))
+        return ms.value
 
     def set_profiling(self, enabled):
         _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))

@@ -122,6 +122,7 @@ def lib():
         L.orc_swarm_get_imu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
         L.orc_swarm_get_external_force.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
         L.orc_swarm_get_pid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
+        L.orc_swarm_set_pid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp]
         L.orc_swarm_get_mixer_allocation.argtypes = [C.c_void_p, C.c_int32, dp]
         L.orc_swarm_get_diag.argtypes = [C.c_void_p, C.POINTER(Diag)]
         L.orc_swarm_get_outputs.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -268,6 +269,9 @@ class OracleSwarm:
         out = np.zeros((count, 24))
         lib().orc_swarm_get_pid(self._h, first, count, _dp(out))
         return out
+
+    def set_pid(self, first, count, pid):
+        lib().orc_swarm_set_pid(self._h, first, count, _dp(_arr(pid, (count, 24))))
 
     def get_mixer_allocation(self, uav):
         n = self.get_params(uav).n_motors

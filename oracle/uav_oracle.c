@@ -832,8 +832,22 @@ static void mixer(uav_t* u) {
     double mn = m[0];
     for (int i = 1; i < n; i++)
       if (m[i] < mn) mn = m[i];
-    if (mn < 0.0)
-      for (int i = 0; i < n; i++) m[i] += fabs(mn);
+    /* mixer.hpp:121 calls UNQUALIFIED abs(min) on a double.  Which overload that is depends on the translation unit: with only
+       <cmath> + <cstdlib> visible it is ::abs(int) (the offset truncates to 0); as soon as a libstdc++ C wrapper header
+       (<stdlib.h> / <math.h>) has been included it is std::abs(double).  Every TU that can hold this line includes Eigen
+       (references.hpp:5), and Eigen/Core includes <emmintrin.h> on x86-64 (SSE2 is on by default), whose <mm_malloc.h> includes
+       <stdlib.h>: the double overload — and ros/ros.h does the same for the nodelet.  That is the flavour restated here
+       (probe recorded in DESIGN.md §9).  -DORC_MIXER_ABS_INT builds the truncating variant (`make -C oracle absint`), kept so that
+       a reference-held fixture, should one ever exist, can settle it; tests/test_oracle_kat.py::test_mixer_desaturation_abs_overload
+       fails if the default build ever truncates. */
+    if (mn < 0.0) {
+#ifdef ORC_MIXER_ABS_INT
+      const double off = (double)abs((int)mn);
+#else
+      const double off = fabs(mn);
+#endif
+      for (int i = 0; i < n; i++) m[i] += off;
+    }
     double mx = m[0];
     for (int i = 1; i < n; i++)
       if (m[i] > mx) mx = m[i];
@@ -1337,6 +1351,19 @@ void orc_swarm_get_pid(const orc_swarm_t* s, int32_t first, int32_t count, doubl
       for (int a = 0; a < 3; a++) {
         pid[24 * k + c * 6 + a * 2 + 0] = sets[c][a].last_error;
         pid[24 * k + c * 6 + a * 2 + 1] = sets[c][a].integral;
+      }
+  }
+}
+/* test hook (the reference has no accessor for the controllers' PID members, pid.hpp:20-21): puts a recorded PID state back, so
+ * that a test can restart both sides from IDENTICAL inputs in the middle of a closed-loop run */
+void orc_swarm_set_pid(orc_swarm_t* s, int32_t first, int32_t count, const double* pid) {
+  for (int k = 0; k < count; k++) {
+    uav_t*       u       = &s->u[first + k];
+    pid_state_t* sets[4] = {u->pid_pos, u->pid_vel, u->pid_att, u->pid_rate};
+    for (int c = 0; c < 4; c++)
+      for (int a = 0; a < 3; a++) {
+        sets[c][a].last_error = pid[24 * k + c * 6 + a * 2 + 0];
+        sets[c][a].integral   = pid[24 * k + c * 6 + a * 2 + 1];
       }
   }
 }

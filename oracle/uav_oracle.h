@@ -148,6 +148,7 @@ void orc_swarm_get_imu(const orc_swarm_t* s, int32_t first, int32_t count, doubl
 void orc_swarm_get_external_force(const orc_swarm_t* s, int32_t first, int32_t count, double* f);
 /* PID states for inspection: count x 24 = {pos,vel,att,rate} x {x,y,z} x {last_error, integral} */
 void orc_swarm_get_pid(const orc_swarm_t* s, int32_t first, int32_t count, double* pid);
+void orc_swarm_set_pid(orc_swarm_t* s, int32_t first, int32_t count, const double* pid);
 /* Mixer::getAllocationMatrix, mixer.hpp:150: n_motors x 4 row-major */
 void orc_swarm_get_mixer_allocation(const orc_swarm_t* s, int32_t uav, double* out);
 void orc_swarm_get_diag(const orc_swarm_t* s, orc_diag_t* out);

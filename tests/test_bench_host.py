@@ -20,6 +20,26 @@ def test_byte_accounting_matches_the_layout():
     assert bench.STATE_BYTES_PER_UAV == 692
     for key in ("actuator", "position"):
         assert bench.BYTES_MOVED_PER_UAV_STEP[key] < bench.BYTES_PER_UAV_STEP[key]
+    # f550 hexarotors (BASELINE configs[1]) and the eight-motor airframe: SURVEY 8d's 908 B / 940 B
+    assert bench.bytes_per_uav_step("position", 6) == 908 and bench.bytes_per_uav_step("position", 8) == 940
+    assert bench.bytes_moved_per_uav_step("position", 6) < 908
+
+
+def test_config2_inputs_are_the_tmux_grid():
+    import numpy as np
+    import bench
+    st, cmd = bench.make_inputs(400, "config2", seed=0)
+    assert st["x"].shape == (400, 3) and np.all(st["x"][:, 2] == 0) and st["x"][:, 0].max() == 76.0 and np.all(st["heading"] == 0)
+    d = np.sort(np.unique(st["x"][:, 0]))
+    assert np.all(np.diff(d) == 4.0)  # 20 x 20, 4 m pitch (tmux/standalone_400_uavs/custom_configs/simulator.yaml)
+    assert np.all(np.abs(cmd[:, :2]) <= 40) and cmd[:, 2].min() >= 2 and cmd[:, 2].max() <= 20 and np.all(np.abs(cmd[:, 3]) <= 3.14)
+
+
+def test_mean_search_candidates_counts_the_27_cell_neighbourhood():
+    import numpy as np
+    import bench
+    x = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [1.5, 0.1, 0.1], [10.0, 10.0, 10.0]])  # cells of edge 1: (0,0,0) x2, (1,0,0), far away
+    assert bench.mean_search_candidates(x, 1.0) == (2 + 2 + 2 + 0) / 4
 
 
 def test_refuses_more_gpus_than_the_machine_has():

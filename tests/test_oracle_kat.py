@@ -242,3 +242,40 @@ def test_crash_zeroes_motors_forever(oracle):
     s.step_n(DT, 200)
     rpm = s.get_state()["motor_rpm"]
     assert rpm[0, 0] > 3000 and rpm[1, 0] < 1171 and list(s.has_crashed()) == [0, 1]
+
+
+def test_mixer_desaturation_abs_overload(oracle, tmp_path):
+    """mixer.hpp:121 `actuators.motors.array() += abs(min)` — UNQUALIFIED abs on a double.  Every TU that holds the line includes
+    Eigen, whose Eigen/Core pulls <emmintrin.h> -> <mm_malloc.h> -> <stdlib.h> on x86-64, which brings std::abs(double) into the
+    global namespace: the offset is |min| (DESIGN.md §9 records the probe).  The oracle must NOT truncate (the int overload would
+    add 0 for any min in (-1, 0)); the truncating reading exists as an oracle-only build (`make -C oracle absint`) and is shown
+    here to differ, so a reference-held fixture could tell the two apart."""
+    import ctypes as C
+    import subprocess
+    O = oracle
+    s = O.OracleSwarm(1)
+    s.construct(0, 1, x500(O), [[0, 0, 0]], [0.0])
+    # x500 rows (roll, pitch, yaw, throttle): (-r,-r,-1,1) (r,r,-1,1) (r,-r,1,1) (-r,r,1,1), r = sqrt(1/2)
+    cg = np.array([[0.0, 0.0, 0.4, 0.1]])  # motors before desaturation: (-0.3, -0.3, 0.5, 0.5): min = -0.3, max after the offset 0.8
+    m = s.debug_component(3, 0, 1, cg)[0, :4]  # MRS_COMP_MIXER
+    assert np.allclose(m, [0.0, 0.0, 0.8, 0.8], atol=1e-15), m
+    # the truncating variant, built on the spot from the same source with -DORC_MIXER_ABS_INT
+    import os
+    src = os.path.join(os.path.dirname(O.__file__), "uav_oracle.c")
+    so = str(tmp_path / "liboracle_absint.so")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-fPIC", "-ffp-contract=off", "-DORC_MIXER_ABS_INT", "-shared", "-o", so, src, "-lm", "-lpthread"])
+    L = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    L.orc_swarm_create.restype = C.c_void_p
+    L.orc_swarm_create.argtypes = [C.c_int32]
+    L.orc_swarm_destroy.argtypes = [C.c_void_p]
+    L.orc_swarm_construct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(O.ModelParams), dp, dp]
+    L.orc_swarm_debug_component.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_double]
+    h = L.orc_swarm_create(1)
+    p = x500(O)
+    pos, hd = np.zeros(3), np.zeros(1)
+    L.orc_swarm_construct(h, 0, 1, C.byref(p), pos.ctypes.data_as(dp), hd.ctypes.data_as(dp))
+    out = np.zeros(8)
+    L.orc_swarm_debug_component(h, 3, 0, 1, cg.ctypes.data_as(dp), 4, out.ctypes.data_as(dp), 8, 0.001)
+    L.orc_swarm_destroy(h)
+    assert np.allclose(out[:4], [-0.3, -0.3, 0.5, 0.5], atol=1e-15), out  # int overload: abs((int)-0.3) == 0, nothing is added
