@@ -416,7 +416,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
             tr, tr_src = pmc_traffic(args, n, workload)
         npad = (n + 63) // 64 * 64
         kernel_name = kernel_name_of(n, workload, arith, args.substeps)
-        # swarm_host.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
+        # tick_single.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1
         if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-steps // args.substeps) >= 4:
             launches_per_step = 2

@@ -17,9 +17,15 @@ UNITS = [
     ("step_kernel_fast.hip", "fast"),
     ("collide.hip", "off"),
     ("outputs.hip", "off"),
-    ("swarm_host.hip", "off"),
+    # host side (no kernels): C ABI, single-GPU tick, sharded tick, the three transports
+    ("host_api.hip", "off"),
+    ("tick_single.hip", "off"),
+    ("tick_sharded.hip", "off"),
+    ("transport_rccl.hip", "off"),
+    ("transport_local.hip", "off"),
+    ("transport_peer.hip", "off"),
 ]
-DEPS = ["step_device.inc", "collide_device.inc", "swarm_layout.h", os.path.join("..", "..", "include", "mrs_swarm.h")]
+DEPS = ["step_device.inc", "collide_device.inc", "swarm_layout.h", "host_internal.h", "sharded_protocol.h", os.path.join("..", "..", "include", "mrs_swarm.h")]
 
 
 def _hipcc():

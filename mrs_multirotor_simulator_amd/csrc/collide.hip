@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
                                               double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id,
                                               uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau) {
   (void)table_id;  // kept in the signature next to the insert kernels' one
-  // A search queued ahead of time (swarm_host.hip) behind fused launches that have turned into no-ops — their lists went stale at
+  // A search queued ahead of time (tick_single.hip) behind fused launches that have turned into no-ops — their lists went stale at
   // an earlier tick — builds its lists as usual (the table protocol stays in step) but must not latch forces or crash flags: the
   // host repeats the search for the tick that stalled, with that tick's own parameters.
   const bool muted = LISTS && stall_word && *stall_word != 0u;
@@ -1482,7 +1482,7 @@ extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w,
   cd->exp_slot = w->exp_slot;
   cd->rebounce = rebounce;
   cd->lim2     = (0.5 * SKIN2) * (0.5 * SKIN2) * (1.0 - 1e-9);
-  cd->lim2_warn = cd->lim2 * (WARN_FRACTION * WARN_FRACTION);  // the warning travels in the collective's headers (swarm_host.hip: export_ticks)
+  cd->lim2_warn = cd->lim2 * (WARN_FRACTION * WARN_FRACTION);  // the warning travels in the collective's headers (tick_sharded.hip: export_ticks)
   cd->tau      = tau;
   cd->n        = sw->n;
   cd->eval     = eval;

@@ -113,7 +113,7 @@ class ShardedSwarm:
 
 # ------------------------------------------------------------------------------------------------------------------------------
 # Export-set exchange driven from Python: the synchronous form of the protocol the library runs natively in
-# mrs_swarm_tick_sharded_n (swarm_host.hip: export_ticks / export_search).  Between two neighbour searches a rank only needs the
+# mrs_swarm_tick_sharded_n (tick_sharded.hip: export_ticks / export_search).  Between two neighbour searches a rank only needs the
 # positions of the foreign UAVs within sqrt(3) + SKIN of one of its own at the last search, and — the relation being symmetric —
 # only has to publish the own UAVs that have such a foreign neighbour.  Per tick:
 #   step -> all-gather of [stale flag | padded export positions]

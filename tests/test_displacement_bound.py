@@ -1,5 +1,5 @@
 """The displacement bound behind the announced stall indices of the split sharded tick (step_device.inc epilogue, TypeParams
-pred_a0 / pred_drag in swarm_host.hip), checked against the ORACLE's dynamics on the CPU: over h steps of RK4 a UAV moves at most
+pred_a0 / pred_drag in host_api.hip derive_type), checked against the ORACLE's dynamics on the CPU: over h steps of RK4 a UAV moves at most
     h dt |v| + (h dt)^2 / 2 * A,   A = A0 + (|resist_k| / m) (|v| + h dt A0)^2,   A0 = g + 1.5 (sum_m alloc[3][m] max_rpm^2 + thrust now) / m + a_ext
 (a_ext: the collision forces' share, listed partners x |rebounce| in the kernel — here an applied force of that size) as long as the
 motor speeds stay within max_rpm (the low-pass keeps them there) and R is near a rotation.  Thousands of random states of three

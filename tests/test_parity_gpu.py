@@ -857,7 +857,7 @@ def test_nan_rollback_inside_a_fused_launch(M, oracle):
 
 @pytest.mark.parametrize("fast", [False, True])
 def test_two_stream_step_runs_equal_single_stream_ones(M, oracle, fast, monkeypatch):
-    """A run of steps is issued as two half-swarm launches per step on two streams (swarm_host.hip); same kernels, same blocks:
+    """A run of steps is issued as two half-swarm launches per step on two streams (tick_single.hip); same kernels, same blocks:
     the results must be bit-identical to the single-stream order, also when other calls are interleaved between the runs."""
     rng = np.random.default_rng(97)
     n = 70_001  # 1094 blocks: above the split threshold, odd block count, ragged tail
