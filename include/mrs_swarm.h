@@ -90,6 +90,18 @@ typedef struct {
   double range;                  /* rangefinder: (z - ground_z)/cos(tilt) + 0.01, >40 -> 41, body_z.z <= 0 -> 41  :403-419 */
 } mrs_uav_output_t;
 
+/* MultirotorModel::State (+ what UavSystemRos::makeStep reads right after it: IMU acceleration, crash flag) of one UAV, packed for
+ * ONE device-to-host copy of a whole range — multirotor_model.hpp:90-98, src/uav_system_ros.cpp:270-282 */
+typedef struct {
+  double  x[3], v[3], v_prev[3];
+  double  R[9];                  /* row-major */
+  double  omega[3];
+  double  motor_rpm[MRS_MAX_MOTORS];
+  double  imu_acceleration[3];   /* UavSystem::getImuAcceleration — uav_system.hpp:424 */
+  int32_t crashed;               /* UavSystem::hasCrashed — uav_system.hpp:286 */
+  int32_t n_motors;
+} mrs_uav_state_t;
+
 typedef struct mrs_swarm mrs_swarm_t;
 
 /* ---- parameter helpers (host only) ---- */
@@ -171,6 +183,10 @@ int mrs_swarm_set_ground_z(mrs_swarm_t* s, int32_t first, int32_t count, double 
 /* for (i) uavs_[i]->makeStep(dt) — src/multirotor_simulator.cpp:211-213 -> UavSystem::makeStep, uav_system.hpp:304-380.
  * Asynchronous on the swarm's stream. */
 int mrs_swarm_step(mrs_swarm_t* s, double dt);
+/* uavs_[i]->makeStep(dt) for the UAVs [first, first + count) ONLY — src/multirotor_simulator.cpp:212 outside a whole-swarm round
+ * (a UAV whose inputs changed after the round's launch, a host that steps one UAV on its own).  Same results as a whole-swarm step
+ * of those UAVs; the neighbour lists of the collision pass are rebuilt at the next collision tick. */
+int mrs_swarm_step_range(mrs_swarm_t* s, int32_t first, int32_t count, double dt);
 /* n_steps consecutive makeStep(dt) rounds; substeps_per_launch > 1 keeps the state in registers across that many
  * steps inside one launch (legal while commands are constant and collisions are off; results identical). */
 int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substeps_per_launch);
@@ -184,6 +200,9 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
  * NULL.  x,v,v_prev,omega: count x 3; R: count x 9 row-major; motor_rpm: count x MRS_MAX_MOTORS. */
 int mrs_swarm_get_state(mrs_swarm_t* s, int32_t first, int32_t count, double* x, double* v, double* v_prev, double* R,
                         double* omega, double* motor_rpm);
+/* the same for a whole range as packed records: one pack kernel, one device-to-host copy (what a per-UAV loop of getState() calls
+ * over a pool of UavSystem objects is served from: uav_system.hpp UavPool) */
+int mrs_swarm_get_states(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_state_t* out);
 /* MultirotorModel::setState — multirotor_model.hpp:424-433 (v_prev untouched, like the reference) */
 int mrs_swarm_set_state(mrs_swarm_t* s, int32_t first, int32_t count, const double* x, const double* v, const double* R,
                         const double* omega, const double* motor_rpm);
@@ -194,6 +213,13 @@ int mrs_swarm_set_pid(mrs_swarm_t* s, int32_t first, int32_t count, const double
 /* an independent copy of the whole swarm on the same device: state, commands, feed-forwards, PIDs, parameters, flags.  The
  * reference's UavSystem is a copy-assignable value (src/uav_system_ros.cpp:105); collision bookkeeping starts afresh in the copy. */
 int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out);
+/* the same with room for more UAVs: the first mrs_swarm_size(s) UAVs are copies, the others UavSystem() — how a pool of
+ * UavSystem objects grows (include/mrs_multirotor_simulator/uav_system/uav_system.hpp UavPool) */
+int mrs_swarm_clone_resized(mrs_swarm_t* s, int32_t n_uavs, mrs_swarm_t** out);
+/* UavSystem copy-assignment between batches: UAVs [src_first, src_first + count) of `src` replace [dst_first, ...) of `dst` — state,
+ * command, feed-forwards, PIDs, flags and parameter set.  The swarms must be clones of each other (mrs_swarm_clone[_resized]: their
+ * parameter tables agree on every index in use; MRS_ERR_TYPES otherwise) on the same device; ranges of one swarm must not overlap. */
+int mrs_swarm_copy_uavs(mrs_swarm_t* dst, int32_t dst_first, mrs_swarm_t* src, int32_t src_first, int32_t count);
 /* UavSystem::getImuAcceleration — uav_system.hpp:424 */
 int mrs_swarm_get_imu(mrs_swarm_t* s, int32_t first, int32_t count, double* imu);
 /* MultirotorModel::getExternalForce — multirotor_model.hpp:452 */

@@ -535,12 +535,15 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   mrs_collide_free(s->cwork);
   if (s->dRec) (void)hipFree(s->dRec);
   if (s->dOut) (void)hipFree(s->dOut);
+  if (s->dSt) (void)hipFree(s->dSt);
+  if (s->hSt) (void)hipHostFree(s->hSt);
   if (s->hOut) (void)hipHostFree(s->hOut);
   if (s->hIn) (void)hipHostFree(s->hIn);
   if (s->dIn) (void)hipFree(s->dIn);
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
+  if (s->dIota) (void)hipFree(s->dIota);
   if (s->dDiag) (void)hipFree(s->dDiag);
   if (s->dF) (void)hipFree(s->dF);
   if (s->dS) (void)hipFree(s->dS);
@@ -875,29 +878,35 @@ int mrs_swarm_set_pid(mrs_swarm_t* s, int32_t first, int32_t count, const double
   return MRS_OK;
 }
 
-int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out) {
+int mrs_swarm_clone_resized(mrs_swarm_t* s, int32_t n_uavs, mrs_swarm_t** out) {
   MRS_ENTER(s);
   if (!s || !out) return fail(MRS_ERR_ARG, "null argument");
+  if (n_uavs < s->n) return fail(MRS_ERR_ARG, "a resized clone holds at least the UAVs of the original");
   *out = nullptr;
   mrs_swarm* c = nullptr;
-  int rc = mrs_swarm_create(s->n, s->device, &c);
+  int rc = mrs_swarm_create(n_uavs, s->device, &c);  // (UAVs beyond the original's: UavSystem(), type 0 of every table)
   if (rc) return rc;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  hipError_t e = hipMemcpyAsync(c->dS, s->dS, sizeof(double) * (size_t)F_COUNT * s->npad, hipMemcpyDeviceToDevice, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(c->dF, s->dF, sizeof(uint32_t) * (size_t)s->npad, hipMemcpyDeviceToDevice, s->stream);
+  // (a larger copy: only the original's UAVs travel — the padding lanes of its last block are real UAVs of the copy and keep their own initial values)
+  const size_t w = (size_t)(n_uavs == s->n ? s->npad : s->n);
+  hipError_t   e = hipMemcpy2DAsync(c->dS, sizeof(double) * (size_t)c->npad, s->dS, sizeof(double) * (size_t)s->npad, sizeof(double) * w, F_COUNT,
+                                    hipMemcpyDeviceToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->dF, s->dF, sizeof(uint32_t) * w, hipMemcpyDeviceToDevice, s->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(c->dDiag, s->dDiag, sizeof(unsigned long long) * 4, hipMemcpyDeviceToDevice, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if (e != hipSuccess) {
     mrs_swarm_destroy(c);
     return fail(MRS_ERR_HIP, std::string("clone: ") + hipGetErrorString(e));
   }
-  c->arith        = s->arith;
-  c->keys         = s->keys;
-  c->tparams      = s->tparams;
-  c->key_index    = s->key_index;
-  c->uav_type     = s->uav_type;
-  c->uav_mode     = s->uav_mode;
+  c->arith     = s->arith;
+  c->keys      = s->keys;  // (index 0 of every table is UavSystem()'s default parameter set: the extra UAVs stay valid)
+  c->tparams   = s->tparams;
+  c->key_index = s->key_index;
+  for (int i = 0; i < s->n; i++) {
+    c->uav_type[(size_t)i] = s->uav_type[(size_t)i];
+    c->uav_mode[(size_t)i] = s->uav_mode[(size_t)i];
+  }
   c->n_cascade    = s->n_cascade;
   c->table_dt     = s->table_dt;
   c->fext_active  = s->fext_active;
@@ -906,6 +915,57 @@ int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out) {
   c->blocks_dirty = true;
   c->nbr_dirty    = true;
   *out = c;
+  return MRS_OK;
+}
+
+int mrs_swarm_clone(mrs_swarm_t* s, mrs_swarm_t** out) {
+  if (!s) return fail(MRS_ERR_ARG, "null argument");
+  return mrs_swarm_clone_resized(s, s->n, out);
+}
+
+int mrs_swarm_copy_uavs(mrs_swarm_t* dst, int32_t dst_first, mrs_swarm_t* src, int32_t src_first, int32_t count) {
+  if (!dst || !src) return fail(MRS_ERR_ARG, "null swarm");
+  // (two swarms: locked in address order, so that two threads copying in opposite directions cannot deadlock)
+  std::unique_lock<std::recursive_mutex> l1((dst < src ? dst : src)->mtx), l2;
+  if (dst != src) l2 = std::unique_lock<std::recursive_mutex>((dst < src ? src : dst)->mtx);
+  dst->op_seq++;
+  src->op_seq++;
+  int rc;
+  if ((rc = settle(src)) || (rc = settle(dst))) return rc;
+  if ((rc = check_range(dst, dst_first, count)) || (rc = check_range(src, src_first, count))) return rc;
+  if (count == 0) return MRS_OK;
+  if (dst->device != src->device) return fail(MRS_ERR_ARG, "copy_uavs: both swarms must live on the same device");
+  if (dst == src && dst_first < src_first + count && src_first < dst_first + count) return fail(MRS_ERR_ARG, "copy_uavs: overlapping ranges of one swarm");
+  HIPCHK(hipSetDevice(dst->device));
+  // the flag words carry indices into the type table: the tables must agree on every index the copied UAVs use (clones of each
+  // other do: tables only ever grow at their end); indices the destination does not have yet are appended in the source's order
+  for (int k = 0; k < count; k++) {
+    const size_t t = src->uav_type[(size_t)src_first + k];
+    while (dst->keys.size() <= t) {
+      const TypeKey& key = src->keys[dst->keys.size()];
+      int            got = -1;
+      if ((rc = intern_type(dst, key, &got))) return rc;
+      if ((size_t)got + 1 != dst->keys.size()) return fail(MRS_ERR_TYPES, "copy_uavs: the two swarms are not clones of each other (their type tables differ)");
+    }
+    if (memcmp(&dst->keys[t], &src->keys[t], sizeof(TypeKey)) != 0)
+      return fail(MRS_ERR_TYPES, "copy_uavs: the two swarms are not clones of each other (their type tables differ)");
+  }
+  HIPCHK(hipStreamSynchronize(src->stream));  // the source columns are complete
+  HIPCHK(hipMemcpy2DAsync(dst->dS + dst_first, sizeof(double) * (size_t)dst->npad, src->dS + src_first, sizeof(double) * (size_t)src->npad,
+                          sizeof(double) * (size_t)count, F_COUNT, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(hipMemcpyAsync(dst->dF + dst_first, src->dF + src_first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(hipStreamSynchronize(dst->stream));  // (the caller may overwrite the source right away)
+  for (int k = 0; k < count; k++) {
+    const uint16_t t = src->uav_type[(size_t)src_first + k];
+    if (dst->uav_type[(size_t)dst_first + k] != t) {
+      dst->uav_type[(size_t)dst_first + k] = t;
+      dst->blocks_dirty = true;
+    }
+  }
+  for (int k = 0; k < count; k++) track_mode(dst, dst_first + k, 1, src->uav_mode[(size_t)src_first + k]);
+  dst->nbr_dirty = true;  // positions changed under the neighbour lists
+  dst->p_valid   = false;
+  dst->fext_active = dst->fext_active || src->fext_active;
   return MRS_OK;
 }
 
@@ -1019,6 +1079,32 @@ int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, con
   if (count == 0) return MRS_OK;
   if ((rc = fetch_outputs(s, first, count))) return rc;
   *view = s->hOut;
+  return MRS_OK;
+}
+
+int mrs_swarm_get_states(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_state_t* out) {
+  MRS_ENTER(s);
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!out) return fail(MRS_ERR_ARG, "null out");
+  if (count == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  if (count > s->st_cap) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->dSt) HIPCHK(hipFree(s->dSt));
+    if (s->hSt) HIPCHK(hipHostFree(s->hSt));
+    s->dSt = nullptr;
+    s->hSt = nullptr;
+    s->st_cap = 0;
+    HIPCHK(hipMalloc(&s->dSt, sizeof(mrs_uav_state_t) * (size_t)count));
+    HIPCHK(hipHostMalloc(&s->hSt, sizeof(mrs_uav_state_t) * (size_t)count, hipHostMallocDefault));
+    s->st_cap = count;
+  }
+  HIPCHK(mrs_launch_pack_states(s->view(), first, count, s->dSt, s->stream));
+  HIPCHK(hipMemcpyAsync(s->hSt, s->dSt, sizeof(mrs_uav_state_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  memcpy(out, s->hSt, sizeof(mrs_uav_state_t) * (size_t)count);
   return MRS_OK;
 }
 

@@ -85,6 +85,7 @@ extern "C" int        mrs_collide_fused_pin(const CollideWork* w);
 extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_unpack_rows(SwarmDev sw, const double* rows, int stride, int width, int base, int first, int count, hipStream_t st);
 extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st);
+extern "C" hipError_t mrs_launch_pack_states(SwarmDev sw, int first, int count, mrs_uav_state_t* dev_out, hipStream_t st);
 extern "C" hipError_t mrs_launch_peer_allgather(const MrsPeerWindows* pw, const void* send, void* recv, size_t bytes, int rank, int world, unsigned seq,
                                                 size_t slot_bytes, unsigned* tickets, unsigned ticket_total, unsigned* err_host, unsigned* bpp_out,
                                                 hipStream_t st);
@@ -219,6 +220,9 @@ struct mrs_swarm {
   mrs_uav_output_t* dOut = nullptr;
   mrs_uav_output_t* hOut = nullptr;
   int32_t           out_cap = 0;
+  mrs_uav_state_t*  dSt = nullptr;   // packed states (mrs_swarm_get_states): device buffer + pinned host staging
+  mrs_uav_state_t*  hSt = nullptr;
+  int32_t           st_cap = 0;
   // staged command upload: pinned host rows + device copy
   double* hIn = nullptr;
   double* dIn = nullptr;
@@ -269,6 +273,8 @@ struct mrs_swarm {
   uint32_t* dBT = nullptr;
   int32_t*  dMB = nullptr;
   bool      blocks_dirty = true;
+  int32_t*  dIota = nullptr;  // 0, 1, 2, ...: block list of a partial step (mrs_swarm_step_range)
+  int       iota_cap = 0;
 
   bool      fext_active = false;  // apply_force / collisions were used at least once
 

@@ -178,6 +178,38 @@ extern "C" hipError_t mrs_launch_timeout_input(SwarmDev sw, int first, int count
   return hipGetLastError();
 }
 
+// MultirotorModel::State + IMU + crash flag of UAVs [first, first + count) as packed records (mrs_uav_state_t)
+namespace {
+__global__ void __launch_bounds__(256) k_pack_states(SwarmDev sw, int first, int count, mrs_uav_state_t* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const int      i  = first + k;
+  const size_t   np = (size_t)sw.npad;
+  const uint32_t fl = sw.F[i];
+  mrs_uav_state_t o;
+#define LD(f) sw.S[(size_t)(f) * np + i]
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    o.x[c] = LD(F_X + c); o.v[c] = LD(F_V + c); o.omega[c] = LD(F_W + c); o.imu_acceleration[c] = LD(F_IMU + c);
+    o.v_prev[c] = (fl & FLAG_VPREV_SPLIT) ? LD(F_VPREV + c) : o.v[c];  // v_prev == v unless setState changed v since the last step
+  }
+#pragma unroll
+  for (int c = 0; c < 9; c++) o.R[c] = LD(F_R + c);
+  const int nm = sw.T[fl >> FLAG_TYPE_SHIFT].n_motors;
+#pragma unroll
+  for (int m = 0; m < MRS_MAX_MOTORS; m++) o.motor_rpm[m] = m < nm ? LD(F_RPM + m) : 0.0;
+#undef LD
+  o.crashed  = (fl & FLAG_CRASHED) ? 1 : 0;
+  o.n_motors = nm;
+  out[k] = o;
+}
+}  // namespace
+extern "C" hipError_t mrs_launch_pack_states(SwarmDev sw, int first, int count, mrs_uav_state_t* dev_out, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_states, dim3((count + 255) / 256), dim3(256), 0, st, sw, first, count, dev_out);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t mrs_launch_pack_outputs(SwarmDev sw, int first, int count, mrs_uav_output_t* dev_out, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_pack_outputs, dim3((count + 255) / 256), dim3(256), 0, st, sw, first, count, dev_out);

@@ -367,6 +367,49 @@ int mrs_swarm_step_n(mrs_swarm_t* s, double dt, int32_t n_steps, int32_t substep
   return finish_profile(s);
 }
 
+// makeStep for the UAVs [first, first + count) ONLY — the reference's per-UAV call `uavs_[i]->makeStep(dt)` (src/multirotor_simulator.cpp:212)
+// when it is not part of a whole-swarm round.  Per-lane airframe constants (the mixed-block kernels) over a view of the state shifted
+// to `first`: any range, any mix of airframes and input modes; results identical to a whole-swarm step of the same UAVs.
+int mrs_swarm_step_range(mrs_swarm_t* s, int32_t first, int32_t count, double dt) {
+  MRS_ENTER(s);  // (a collision tick still pending is evaluated first: its forces act on this step)
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!(dt > 0)) return fail(MRS_ERR_ARG, "bad step arguments");
+  if (count == 0) return MRS_OK;
+  if (first == 0 && count == s->n) return mrs_swarm_step_n(s, dt, 1, 1);
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = upload_types(s, dt))) return rc;
+  const int nb = (count + 63) / 64;
+  if (nb > s->iota_cap) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->dIota) HIPCHK(hipFree(s->dIota));
+    s->dIota = nullptr;
+    int cap = 16;
+    while (cap < nb) cap *= 2;
+    std::vector<int32_t> iota((size_t)cap);
+    for (int b = 0; b < cap; b++) iota[(size_t)b] = b;
+    HIPCHK(hipMalloc(&s->dIota, sizeof(int32_t) * (size_t)cap));
+    HIPCHK(hipMemcpy(s->dIota, iota.data(), sizeof(int32_t) * (size_t)cap, hipMemcpyHostToDevice));
+    s->iota_cap = cap;
+  }
+  SwarmDev v = s->view();
+  v.S += first;  // column f of UAV first + i sits at S[f * npad + first + i]: the same stride, shifted base
+  v.F += first;
+  v.n       = count;
+  v.MB      = s->dIota;
+  v.n_mixed = nb;
+  v.BT      = nullptr;  // (mixed-block kernels read the airframe type per lane, from the flag word)
+  v.vl_rec  = nullptr;  // no skin test in a partial step: the next collision tick searches (nbr_dirty below)
+  v.vl_flag = nullptr;
+  if (s->arith == MRS_ARITH_FAST)
+    HIPCHK(mrs_launch_step_fast(v, dt, 1, 0, 0, 0, 1, s->stream));
+  else
+    HIPCHK(mrs_launch_step_literal(v, dt, 1, 0, 0, 0, 1, s->stream));
+  s->p_valid   = false;
+  s->nbr_dirty = true;
+  return MRS_OK;
+}
+
 int mrs_swarm_step(mrs_swarm_t* s, double dt) {
   MRS_LOCK(s); return mrs_swarm_step_n(s, dt, 1, 1); }
 

@@ -99,8 +99,11 @@ ABI_SYMBOLS = [
     "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
-    "mrs_swarm_debug_search_ms",
+    "mrs_swarm_debug_search_ms", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
 ]
+
+STATE_DTYPE = np.dtype([("x", "f8", 3), ("v", "f8", 3), ("v_prev", "f8", 3), ("R", "f8", (3, 3)), ("omega", "f8", 3), ("motor_rpm", "f8", 8),
+                        ("imu_acceleration", "f8", 3), ("crashed", "i4"), ("n_motors", "i4")])
 
 _lib = None
 # mrs_allgather_fn: int (*)(void* user, const void* send, void* recv, uint64_t bytes_per_rank, void* stream)
@@ -278,6 +281,10 @@ def load_library():
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
         "mrs_swarm_debug_search_ms": [vp, i32, i32, f64, dp],
+        "mrs_swarm_clone_resized": [vp, i32, C.POINTER(vp)],
+        "mrs_swarm_copy_uavs": [vp, i32, vp, i32, i32],
+        "mrs_swarm_step_range": [vp, i32, i32, f64],
+        "mrs_swarm_get_states": [vp, i32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -570,6 +577,29 @@ class Swarm:
         other.n = self.n
         _check(_lib.mrs_swarm_clone(self._h, C.byref(other._h)))
         return other
+
+    def clone_resized(self, n_uavs):
+        """a copy with room for more UAVs (mrs_swarm_clone_resized): the first self.n are copies, the rest UavSystem()"""
+        other = object.__new__(Swarm)
+        other._h = C.c_void_p()
+        other.n = int(n_uavs)
+        _check(_lib.mrs_swarm_clone_resized(self._h, int(n_uavs), C.byref(other._h)))
+        return other
+
+    def copy_uavs(self, dst_first, src, src_first, count):
+        """UAVs [src_first, src_first + count) of `src` (a clone of this swarm, or this swarm) replace [dst_first, ...) here"""
+        _check(_lib.mrs_swarm_copy_uavs(self._h, int(dst_first), src._h, int(src_first), int(count)))
+
+    def step_range(self, first, count, dt):
+        """makeStep for the UAVs [first, first + count) only (mrs_swarm_step_range)"""
+        _check(_lib.mrs_swarm_step_range(self._h, int(first), int(count), float(dt)))
+
+    def get_states(self, first=0, count=None):
+        """packed MultirotorModel::State + IMU + crash flag records (mrs_swarm_get_states): one kernel, one copy"""
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=STATE_DTYPE)
+        _check(_lib.mrs_swarm_get_states(self._h, int(first), int(count), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def timeout_input(self, first, count):
         _check(_lib.mrs_swarm_timeout_input(self._h, first, count))
