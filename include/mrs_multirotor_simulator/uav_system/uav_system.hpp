@@ -181,7 +181,7 @@ public:
     }
     const bool again = round_of_[(size_t)slot] == round_;  // this object has made its step of the running round: the next round begins
     if (again && !speculate_) {  // observing: has every object stepped since this one stepped last?
-      if (seen_in_round_ == n_live_) speculate_ = true;
+      if (seen_in_round_ == n_live_ && allow_speculation_) speculate_ = true;
       round_++;
       seen_in_round_ = 0;
     }

@@ -378,8 +378,9 @@ __global__ void __launch_bounds__(256) k_own_bbox_part(const PosRecord* rec, lon
   }
 }
 // stage 2: the box, widened by `margin`
-__global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, double margin, double* bb, const uint32_t* ctl, int cur, int force) {
+__global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, double margin, double* bb, uint32_t* ctl, int cur, int force) {
   __shared__ double lo[3][256], hi[3][256];
+  if (force && threadIdx.x == 0) ctl[cur ^ 1] = 0u;  // (a decided search: the flag word this tick's query may raise starts from 0 — k_skin_gathered's other job)
   if (!force && ctl[cur] == 0u) return;
   double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
   if (threadIdx.x < BBOX_BLOCKS)
@@ -987,8 +988,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   if (!w->g_bbox) CK(hipMalloc(&w->g_bbox, sizeof(double) * 6 * (BBOX_BLOCKS + 1)));  // the box, then the partial boxes
   if (force) {
     // (the search is decided: the comparison of all records with those of the last search would only cost time — 14 us at 1 M records;
-    //  its other job, clearing the flag word the query may raise, is one memset)
-    CK(hipMemsetAsync(w->ctl + (w->fcur ^ 1), 0, sizeof(uint32_t), st));
+    //  its other job, clearing the flag word the query may raise, is done by k_own_bbox_final)
   } else {
     hipLaunchKernelGGL(k_skin_gathered, dim3(gN), dim3(256), 0, st, rec, w->g_rec_build, n_total, w->ctl, w->fcur, lim2);
   }
@@ -1070,18 +1070,29 @@ __global__ void k_fill_positions(SwarmDev sw, Pos4* pos_now) {
   pos_now[i]      = pp;
 }
 
-__global__ void k_search_reset(uint32_t* fctl, uint32_t* map, long long n_map, uint32_t* blk_class, int n_blocks) {
+// one launch: control words (the error word stays: it is reported at the end of the call), slot map (padding UAVs: no slot), block
+// classes, and the export allocation — send block, gathered blocks, partner constants — zeroed (headers!)
+__global__ void k_search_reset(uint32_t* fctl, uint32_t* map, long long n_map, uint32_t* blk_class, int n_blocks, uint4* xalloc, long long n_xvec) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_map) map[i] = MRS_NO_SLOT;
   if (i < n_blocks) blk_class[i] = 0u;
   if (i < CTL_WORDS && i != CTL_ERROR) fctl[i] = 0u;
+  for (long long v = i; v < n_xvec; v += (long long)gridDim.x * blockDim.x) xalloc[v] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // map: [0] export count of this rank, [1] lanes over the list capacity so far, [2 + i] slot of own UAV i
-__global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot, uint32_t* map,
-                              uint32_t* fctl, uint32_t* blk_class) {
+// ... and the position records of the UAVs as the search found them (what the first fused launch after the search reads)
+__global__ void k_export_mark(SwarmDev sw, Pos4* pos_now, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot,
+                              uint32_t* map, uint32_t* fctl, uint32_t* blk_class) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = sw.n;
   if (i >= n) return;
+  {
+    const size_t np = (size_t)sw.npad;
+    const Pos4   pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i],
+                       (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};
+    pos_now[i]      = pp;
+  }
   const uint32_t cnt = nbr_cnt[i];
   bool           exported = false;
   for (uint32_t k = 0; k < cnt; k++) {
@@ -1096,27 +1107,15 @@ __global__ void k_export_mark(int n, long long n_max, int rank, const uint32_t* 
 }
 
 // the boundary blocks in a list (any order), their number in the control word the host reads with the export counts
-__global__ void k_class_list(int n_blocks, const uint32_t* blk_class, uint32_t* blk_list, uint32_t* fctl) {
+// ... and the head of the rank's slot map (export count — final: the marking launch is complete —, lanes over the list capacity)
+__global__ void k_class_list(int n_blocks, const uint32_t* blk_class, uint32_t* blk_list, uint32_t* fctl, uint32_t* map, const uint32_t* ctl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) {
+    map[0] = fctl[CTL_EXPORTS];
+    map[1] = ctl[6];  // lanes over the list capacity (cumulative, collide.hip k_query)
+  }
   if (b >= n_blocks) return;
   if (blk_class[b] & MRS_BLK_BOUNDARY) blk_list[atomicAdd(&fctl[CTL_NBND], 1u)] = (uint32_t)b;
-}
-
-// interior blocks that list a UAV of a boundary block (translated lists: a local entry is the UAV's index)
-__global__ void k_class_layer1(int n, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* blk_class, uint32_t* fctl) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || (blk_class[i >> 6] & MRS_BLK_BOUNDARY)) return;
-  const uint32_t cnt = nbr_cnt[i];
-  bool           l1  = false;
-  for (uint32_t k = 0; k < cnt; k++) {
-    const uint32_t e = nbr[(size_t)k * (size_t)n + (size_t)i];
-    if (!(e & MRS_NBR_FOREIGN) && (blk_class[e >> 6] & MRS_BLK_BOUNDARY)) l1 = true;
-  }
-  if (l1 && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
-}
-// the layer-1 block count where the host reads it without a synchronisation of its own (it looks after the serial ticks that follow a search)
-__global__ void k_layer1_to_host(const uint32_t* fctl, volatile uint32_t* hostw) {
-  __hip_atomic_store(&hostw[CTL_NL1], fctl[CTL_NL1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet
@@ -1126,22 +1125,24 @@ __global__ void k_handoff_init(uint32_t* fctl, uint32_t* epoch, int n_blocks, ui
   if (b == 0) fctl[CTL_I_STARTED] = tau;
 }
 
-__global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint32_t* ctl) {
+__global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint32_t* ctl) {  // (a rank without UAVs)
   map[0] = fctl[CTL_EXPORTS];
-  map[1] = ctl[6];  // lanes over the list capacity (cumulative, collide.hip k_query)
+  map[1] = ctl[6];
 }
 
 __global__ void k_export_translate(int n, long long n_max, int rank, long long map_stride, int block, uint32_t* nbr, const uint32_t* nbr_cnt,
-                                   const uint32_t* maps, const PosRecord* rec_all, Pos4* x_recv, PartnerConst* x_const, uint32_t* fctl) {
+                                   const uint32_t* maps, const PosRecord* rec_all, Pos4* x_recv, PartnerConst* x_const, uint32_t* fctl, uint32_t* blk_class) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t cnt = nbr_cnt[i];
+  bool           l1  = false;  // this UAV lists a UAV of a boundary block (the classes of the marking launch are complete)
   for (uint32_t k = 0; k < cnt; k++) {
     const size_t    at = (size_t)k * (size_t)n + (size_t)i;
     const uint32_t  g  = nbr[at];
     const long long q  = (long long)g / n_max, j = (long long)g - q * n_max;
     if (q == (long long)rank) {
       nbr[at] = (uint32_t)j;
+      if (blk_class[j >> 6] & MRS_BLK_BOUNDARY) l1 = true;
       continue;
     }
     const uint32_t e = maps[(size_t)q * (size_t)map_stride + 2 + (size_t)j];
@@ -1158,6 +1159,9 @@ __global__ void k_export_translate(int n, long long n_max, int rank, long long m
     x_recv[slot]  = pp;
     x_const[slot] = cc;
   }
+  // interior blocks that list a UAV of a boundary block wait for that block's epoch word in a split tick (MRS_BLK_LAYER1); their
+  // number goes to the host with the first fused launch after the search (CTL_NL1: the residency bound of the split form)
+  if (l1 && !(blk_class[i >> 6] & MRS_BLK_BOUNDARY) && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
 }
 
 // handleCollisions of the tick after the most recent step, evaluated on its own from the lists (local partners: position records,
@@ -1222,7 +1226,8 @@ __global__ void k_fold_stall(const Pos4* x_recv, int world, int block, Pos4* x_s
 }  // namespace
 
 // sizes of the export-set exchange for `world` ranks and `cap` export slots per rank; buffers zeroed (headers!)
-extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, hipStream_t st) {
+// zero == 0: the caller's next launch is the search's reset kernel, which zeroes the allocation itself (one launch less per search)
+extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, int zero, hipStream_t st) {
   if (!*work) *work = new CollideWork();
   CollideWork* w = *work;
   CK(ensure_fused(w, sw.n > 0 ? sw.n : 1, st));
@@ -1257,7 +1262,7 @@ extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work
   }
   const size_t block = (size_t)w->x_cap + 1;
   static_assert(sizeof(Pos4) == sizeof(PartnerConst), "one stride for the three parts of the export allocation");
-  CK(hipMemsetAsync(w->x_send, 0, sizeof(Pos4) * block * (size_t)(1 + 2 * world), st));
+  if (zero) CK(hipMemsetAsync(w->x_send, 0, sizeof(Pos4) * block * (size_t)(1 + 2 * world), st));
   return hipSuccess;
 }
 
@@ -1430,37 +1435,43 @@ extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* 
   return hipGetLastError();
 }
 
+extern "C" const uint32_t* mrs_collide_host_heads(const CollideWork* w) { return w ? w->host_heads : nullptr; }
+// a search has replaced the lists: launch indices restart at 1, the pinned mirrors of the control words start from nothing
+extern "C" void mrs_collide_host_words_reset(CollideWork* w) {
+  if (!w || !w->hostw) return;
+  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
+  w->hostw[CTL_NL1] = 0xFFFFFFFFu;  // "not known yet": k_layer1_to_host writes the count at the end of the search
+}
 extern "C" long long mrs_collide_export_capacity(const CollideWork* w) { return w ? w->x_cap : 0; }
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w) { return w ? w->fctl : nullptr; }
 extern "C" void*     mrs_collide_export_send(const CollideWork* w) { return w ? (void*)w->x_send : nullptr; }
 extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? (void*)w->x_recv : nullptr; }
 
 // after a search over gathered records: mark the export set, write this rank's slot map (2 + n_max words) for the all-gather
-extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st) {
-  // control words (the error word stays: it is reported at the end of the call), slot map (padding UAVs: no slot), block classes: ONE launch
-  hipLaunchKernelGGL(k_search_reset, dim3((unsigned)((n_max + 2 + 255) / 256)), dim3(256), 0, st, w->fctl, map_send, n_max + 2, w->blk_class,
-                     (sw.n + 63) / 64);
-  w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
-  w->hostw[CTL_NL1] = 0xFFFFFFFFu;  // "not known yet": k_layer1_to_host writes the count at the end of the search
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, hipStream_t st) {
+  // (the host mirrors of the control words are reset by the host once it has read what the old segment left in them: mrs_collide_host_words_reset)
+  const long long n_xvec = (long long)(sizeof(Pos4) * ((size_t)w->x_cap + 1) * (size_t)(1 + 2 * w->x_world) / sizeof(uint4));
+  long long       grid   = (map_words + 255) / 256;
+  if (grid < 64) grid = 64;
+  hipLaunchKernelGGL(k_search_reset, dim3((unsigned)grid), dim3(256), 0, st, w->fctl, map_send, map_words, w->blk_class, (sw.n + 63) / 64, (uint4*)w->x_send, n_xvec);
   if (sw.n > 0) {
     const int n_blocks = (sw.n + 63) / 64;
-    hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send, w->fctl,
-                       w->blk_class);
-    hipLaunchKernelGGL(k_class_list, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, w->blk_class, w->blk_list, w->fctl);
-    hipLaunchKernelGGL(k_fill_positions, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur]);
+    hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur], n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send,
+                       w->fctl, w->blk_class);
+    hipLaunchKernelGGL(k_class_list, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, w->blk_class, w->blk_list, w->fctl, map_send,
+                       w->ctl ? w->ctl : w->fctl);
+  } else {
+    hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, st, map_send, w->fctl, w->ctl ? w->ctl : w->fctl);  // (never searched: word 6 of fctl is 0)
   }
-  hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, st, map_send, w->fctl, w->ctl ? w->ctl : w->fctl);  // (a rank without UAVs never searched: word 6 of fctl is 0)
   return hipGetLastError();
 }
 
 // after the all-gather of the slot maps (and with buffers of sufficient capacity): rewrite the lists, seed the gathered export buffer
-extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, int rank, const uint32_t* maps, const PosRecord* rec_all,
-                                                   hipStream_t st) {
+extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, long long map_stride, int rank, const uint32_t* maps,
+                                                   const PosRecord* rec_all, hipStream_t st) {
   if (sw.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, n_max + 2, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
-                     maps, rec_all, w->x_recv, w->x_const, w->fctl);
-  hipLaunchKernelGGL(k_class_layer1, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, w->nbr, w->nbr_cnt, w->blk_class, w->fctl);
-  hipLaunchKernelGGL(k_layer1_to_host, dim3(1), dim3(1), 0, st, w->fctl, w->hostw);
+  hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, map_stride, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
+                     maps, rec_all, w->x_recv, w->x_const, w->fctl, w->blk_class);
   return hipGetLastError();
 }
 

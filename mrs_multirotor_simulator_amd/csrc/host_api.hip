@@ -505,6 +505,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   if (const char* e = getenv("MRS_FUSED_COLLISIONS")) s->use_fused = atoi(e) != 0;
   if (const char* e = getenv("MRS_FUSED_LEAD")) s->fused_lead = atoi(e) > 0 ? atoi(e) : 1;
   if (const char* e = getenv("MRS_SHARD_SPLIT")) s->shard_split = atoi(e) != 0;
+  if (const char* e = getenv("MRS_EARLY_SEARCH")) s->early_search = atoi(e) != 0;
   if (const char* e = getenv("MRS_SHARD_SPLIT_MIN_BLOCKS")) s->split_min_blocks = atoi(e) > 0 ? atoi(e) : 1;
   if (const char* e = getenv("MRS_SHARD_SPLIT_MAX_FRACTION")) s->split_max_fraction = atof(e);
   HIPCHK(hipMalloc(&s->dS, sizeof(double) * (size_t)F_COUNT * s->npad));

@@ -52,13 +52,15 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
                                             hipStream_t st);
 extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** work, const PosRecord* rec, long long n_total, long long my_offset,
                                                      int crash, double rebounce, int force_rebuild, hipStream_t st);
-extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_prepare(SwarmDev sw, CollideWork** work, int world, long long cap, int zero, hipStream_t st);
 extern "C" long long  mrs_collide_export_capacity(const CollideWork* w);
+extern "C" const uint32_t* mrs_collide_host_heads(const CollideWork* w);
+extern "C" void       mrs_collide_host_words_reset(CollideWork* w);
 extern "C" void*      mrs_collide_export_send(const CollideWork* w);
 extern "C" void*      mrs_collide_export_recv(const CollideWork* w);
-extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, int rank, uint32_t* map_send, hipStream_t st);
-extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, int rank, const uint32_t* maps, const PosRecord* rec_all,
-                                                   hipStream_t st);
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, long long map_stride, int rank, const uint32_t* maps,
+                                                   const PosRecord* rec_all, hipStream_t st);
 extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w, long long my_offset, unsigned tau, int eval, int crash, double rebounce,
                                              CollDev* cd);
 extern "C" hipError_t mrs_collide_export_eval(SwarmDev sw, CollDev cd, hipStream_t st);
@@ -191,6 +193,7 @@ struct mrs_swarm {
   int64_t   x_searches = 0, x_ticks = 0, x_noop_ticks = 0;
   // split sharded ticks: between two searches the blocks that hold a boundary UAV are stepped by a small launch on
   // `stream`, followed there by the collective, while the interior launch runs on `stream2` and never waits for a collective
+  bool      early_search = true;    // tuning: MRS_EARLY_SEARCH=0 — a certain search waits for the segment's synchronisation (round 3)
   bool      shard_split = true;     // tuning: MRS_SHARD_SPLIT=0 keeps every tick in the serial form (fused launch, then the collective)
   int       split_min_blocks = 512; // tuning / tests: MRS_SHARD_SPLIT_MIN_BLOCKS
   double    split_max_fraction = 0.25;  // ... and MRS_SHARD_SPLIT_MAX_FRACTION: the boundary launch may cover at most this share of the blocks
@@ -340,5 +343,7 @@ void peer_release(mrs_swarm* s);
 int  comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes);
 int  comm_setup(mrs_swarm* s, int world, int rank, int64_t n_total);
 int  comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total);
+// words of one rank's slot map in the collective of a search: [export count, overflow count, n_max slots], padded to whole 16-byte units
+inline int64_t map_stride(const mrs_swarm* s) { return (s->comm_n_max + 2 + 3) & ~(int64_t)3; }
 }  // namespace mrs_host
 using namespace mrs_host;

@@ -40,8 +40,9 @@ int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   if (const char* e = getenv("MRS_EXCHANGE")) s->exchange = atoi(e) == 1 ? MRS_EXCHANGE_FULL_GATHER : MRS_EXCHANGE_EXPORT_SETS;
   HIPCHK(hipMalloc(&s->comm_send, sizeof(PosRecord) * (size_t)s->comm_n_max));
   HIPCHK(hipMalloc(&s->comm_recv, sizeof(PosRecord) * (size_t)s->comm_n_max * (size_t)world));
-  HIPCHK(hipMalloc(&s->x_map_send, sizeof(uint32_t) * (size_t)(s->comm_n_max + 2)));
-  HIPCHK(hipMalloc(&s->x_map_recv, sizeof(uint32_t) * (size_t)(s->comm_n_max + 2) * (size_t)world));
+  HIPCHK(hipMalloc(&s->x_map_send, sizeof(uint32_t) * (size_t)map_stride(s)));
+  HIPCHK(hipMalloc(&s->x_map_recv, sizeof(uint32_t) * (size_t)map_stride(s) * (size_t)world));
+  HIPCHK(hipMemsetAsync(s->x_map_recv, 0, sizeof(uint32_t) * (size_t)map_stride(s) * (size_t)world, s->stream));  // (the stand-in collective leaves absent ranks' maps alone)
   HIPCHK(hipMemsetAsync(s->comm_send, 0xFF, sizeof(PosRecord) * (size_t)s->comm_n_max, s->stream));  // NaN padding records never collide
   return MRS_OK;
 }
@@ -120,7 +121,7 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
     out->export_capacity   = mrs_collide_export_capacity(s->cwork);
     out->export_count      = s->x_export_count;
     out->bytes_per_tick    = (int64_t)sizeof(Pos4) * (1 + out->export_capacity);
-    out->bytes_per_rebuild = full + (int64_t)sizeof(uint32_t) * (s->comm_n_max + 2);
+    out->bytes_per_rebuild = full + (int64_t)sizeof(uint32_t) * map_stride(s);
   } else {
     out->bytes_per_tick = out->bytes_per_rebuild = full;
   }
@@ -181,12 +182,13 @@ int full_gather_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Col
 // The tick after the most recent step on the SEARCH path of the export-set exchange: gather all records, search (which evaluates
 // this tick's handleCollisions), then derive the export sets and rewrite the lists.  Collective.  Returns 1 when the lists came out
 // incomplete (a UAV with more neighbours than its list holds, on any rank): the caller stays on the full exchange for a while.
-int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
+// first half: everything up to the point where the host needs numbers of its own — ENQUEUED only (no host wait), so that a search
+// that is certain can follow the last launches of a segment in stream order and the segment's one synchronisation serves both
+int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c) {
   const int     world = s->comm_world, rank = s->comm_rank;
-  const int64_t n_max = s->comm_n_max, n_rec = n_max * world, stride = n_max + 2;
+  const int64_t n_max = s->comm_n_max, n_rec = n_max * world, stride = map_stride(s);
   int           rc;
-  *incomplete = 0;
-  s->x_ok     = false;
+  s->x_ok = false;
   s->x_searches++;
   if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
   if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)n_max))) return rc;
@@ -194,14 +196,25 @@ int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
   s->nbr_dirty   = true;  // (a later single-GPU tick starts from a search of its own)
   if (s->n > 0)
     HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
-  long long cap = mrs_collide_export_capacity(s->cwork);
-  HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, s->stream));
-  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, rank, s->x_map_send, s->stream));
+  const long long cap = mrs_collide_export_capacity(s->cwork);
+  HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, /*zero=*/0, s->stream));  // (zeroed by the marking launches)
+  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, stride, rank, s->x_map_send, s->stream));
   if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
   // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
-  const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch)
+  const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch; valid once the stream has been synchronised)
   HIPCHK(mrs_collide_heads_to_host(s->cwork, s->x_map_recv, stride, world, &heads, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
+  return MRS_OK;
+}
+
+// second half, behind a synchronisation of the stream: capacities, then the lists go into export form
+int export_search_finish(mrs_swarm* s, int* incomplete) {
+  const int       world = s->comm_world, rank = s->comm_rank;
+  const int64_t   n_max = s->comm_n_max;
+  const uint32_t* heads = mrs_collide_host_heads(s->cwork);
+  *incomplete = 0;
+  if (!heads) return fail(MRS_ERR_HIP, "export-set search: no head words");
+  mrs_collide_host_words_reset(s->cwork);  // launch indices restart at 1: the host mirrors of the old segment's words are void
+  const long long cap = mrs_collide_export_capacity(s->cwork);
   s->x_nbnd = s->n > 0 ? heads[2 * world] : 0u;
   long long need = 0;
   for (int q = 0; q < world; q++) {
@@ -216,13 +229,20 @@ int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
   }
   if (need > cap || cap == 0) {  // grow with headroom: the sets change from search to search
     long long ncap = ((need + need / 2 + 64 + 63) / 64) * 64;
-    HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, ncap, s->stream));
+    HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, ncap, /*zero=*/1, s->stream));
   }
-  HIPCHK(mrs_collide_export_translate(s->view(), s->cwork, n_max, rank, s->x_map_recv, s->comm_recv, s->stream));
+  HIPCHK(mrs_collide_export_translate(s->view(), s->cwork, n_max, map_stride(s), rank, s->x_map_recv, s->comm_recv, s->stream));
   // (the lists are in export form now; collide.hip remembers that, and the full exchange would start with a search of its own)
   s->x_ok = true;
   s->tau  = 0;
   return MRS_OK;
+}
+
+int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
+  int rc = export_search_enqueue(s, c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return export_search_finish(s, incomplete);
 }
 
 int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval) {
@@ -399,19 +419,30 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       if ((rc = comm_allgather(s, mrs_collide_export_send(s->cwork), mrs_collide_export_recv(s->cwork), bytes))) return rc;
     }
     HIPCHK(mrs_collide_export_fold_stall(s->cwork, 0u, s->stream));
+    // A search that is CERTAIN — this host has seen a stall index, or a warning ended the segment before the call's last tick (every
+    // rank will find the same after the fold: words only ever appear) — follows in stream order, and the one synchronisation below
+    // serves the segment and the search.  It runs on whatever state the launches left: the state after step T when launches after T
+    // turned into no-ops, which is the state the search belongs on either way.
+    const unsigned launched = s->tau + 1 - first;
+    const bool     early_search = s->early_search && mrs_protocol::search_due(stall_word(hw), warn_word(hw), done + (int)launched < n_ticks);
+    if (early_search && (rc = export_search_enqueue(s, c))) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     const unsigned T = stall_word(hw), W = warn_word(hw);  // identical on every rank
-    const unsigned launched = s->tau + 1 - first;
     const unsigned ran = mrs_protocol::ticks_ran(T, first, launched);
     done += (int)ran;
     s->x_ticks += ran;
     s->collision_ticks += ran;
     s->x_noop_ticks += launched - ran;
+    if (early_search && !mrs_protocol::search_due(T, W, done < n_ticks)) return fail(MRS_ERR_HIP, "export-set exchange: a search was queued that the folded words do not ask for");
     if (mrs_protocol::search_due(T, W, done < n_ticks)) {
       // the lists are stale after step T / about to be: all ranks search on the state they have now, which also evaluates the
       // collision tick that followed the last step that ran
       int incomplete = 0;
-      if ((rc = export_search(s, c, &incomplete))) return rc;
+      if (early_search) {
+        if ((rc = export_search_finish(s, &incomplete))) return rc;
+      } else if ((rc = export_search(s, c, &incomplete))) {
+        return rc;
+      }
       pending = false;
       serial_left = (int)MRS_PRED_HORIZON;
       if (incomplete) s->x_fallback_left = 64;

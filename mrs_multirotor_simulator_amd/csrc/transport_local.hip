@@ -118,7 +118,7 @@ int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* 
 // images' only at a search; between searches they read as far away — fine for a time measurement, meaningless as a simulation).
 int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
   const bool records = bytes == sizeof(PosRecord) * (size_t)s->comm_n_max;
-  if (bytes % 16 != 0) {  // (the slot maps: 4 * (n_max + 2) bytes) plain copies, no latency worth modelling on a search tick
+  if (bytes % 16 != 0) {  // (a block that is no whole number of 16-byte units — none of the library's own collectives any more) plain copies
     HIPCHK(hipMemsetAsync(recv, 0, bytes * (size_t)s->comm_world, s->cstream));
     for (int d = -1; d <= 1; d++)
       if (s->comm_rank + d >= 0 && s->comm_rank + d < s->comm_world)

@@ -87,8 +87,9 @@ def test_unchanged_per_uav_loop_over_pooled_objects(mrs, oracle):
         seen += 1
     assert seen == 9
     # launches: every timed tick is ONE round (step launch + state pack = two kernels) but for the disturbances
-    assert timed["rounds"] >= timed["ticks"] - 3 and timed["single_steps"] <= 6, (timed, st)
-    assert st["rollbacks"] <= 8 and st["state_misses"] <= 16 and st["state_hits"] >= 0.98 * n * ticks, st
+    assert timed["rounds"] >= timed["ticks"] - 3 and timed["single_steps"] <= 8, (timed, st)
+    # (the first tick after construction is the pool's observation round: every object steps on its own and reads the device once)
+    assert st["rollbacks"] <= 8 and st["single_steps"] <= n + 8 and st["state_misses"] <= n + 16 and st["state_hits"] >= 0.98 * n * (ticks - 1), st
     print("facade loop:", " ".join(stats["LATENCY_US_PER_CALL"]), "us per makeStep + getState call,", " ".join(stats["TICK_US"]), "us per 400-UAV tick;", st)
     # the same objects stepped one by one (what every facade call cost before the pool): a launch + a synchronisation per call
     single = subprocess.run([exe, "single"], capture_output=True, text=True, check=True, timeout=600).stdout

@@ -112,9 +112,10 @@ def test_copy_uavs_and_resized_clone(mrs, oracle):
     assert big.get_params(12).n_motors == 6 and big.get_params(9).n_motors == 4
     with pytest.raises(M.MrsError):
         big.copy_uavs(0, big, 10, 20)  # overlapping ranges of one swarm
-    other = M.Swarm(64)  # not a clone: its parameter table differs as soon as the range uses anything but UavSystem()'s defaults
+    other = M.Swarm(64)  # not a clone: index 1 of its parameter table is an a300, index 1 of the pair's tables an x500
+    other.construct(0, 64, M.model_params("a300"))
     with pytest.raises(M.MrsError):
-        other.copy_uavs(0, p.g, 80, 10)
+        big.copy_uavs(0, other, 0, 10)
 
 
 def test_get_states_packs_state_imu_and_crash_flag(mrs, oracle):
