@@ -1082,18 +1082,37 @@ __global__ void k_search_reset(uint32_t* fctl, uint32_t* map, long long n_map, u
 
 // map: [0] export count of this rank, [1] lanes over the list capacity so far, [2 + i] slot of own UAV i
 // ... and the position records of the UAVs as the search found them (what the first fused launch after the search reads)
+// ... and the displacement bound on the state the search found (pred_hdt >= 0): the lists are new, every UAV sits on its reference
+// position — if nobody can leave its skin within MRS_PRED_HORIZON steps, no stall index <= MRS_PRED_HORIZON can exist and the ticks
+// right after the search need no serial phase (CTL_PRED, sent to every rank with the head of the slot map)
 __global__ void k_export_mark(SwarmDev sw, Pos4* pos_now, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* exp_slot,
-                              uint32_t* map, uint32_t* fctl, uint32_t* blk_class) {
+                              uint32_t* map, uint32_t* fctl, uint32_t* blk_class, double pred_hdt, double pred_lim, double rebounce) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = sw.n;
   if (i >= n) return;
+  const size_t   np = (size_t)sw.npad;
+  const uint32_t fl = sw.F[i];
+  double         y[18];
+#pragma unroll
+  for (int c = 0; c < 18; c++) y[c] = (pred_hdt >= 0.0 || c < 3) ? sw.S[(size_t)(c < 6 ? F_X + c : (c < 15 ? F_R + (c - 6) : F_W + (c - 15))) * np + i] : 0.0;
   {
-    const size_t np = (size_t)sw.npad;
-    const Pos4   pp = {sw.S[(size_t)(F_X + 0) * np + i], sw.S[(size_t)(F_X + 1) * np + i], sw.S[(size_t)(F_X + 2) * np + i],
-                       (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};
-    pos_now[i]      = pp;
+    const Pos4 pp = {y[0], y[1], y[2], (double)(fl >> FLAG_TYPE_SHIFT)};
+    pos_now[i]    = pp;
   }
   const uint32_t cnt = nbr_cnt[i];
+  if (pred_hdt >= 0.0) {
+    const TypeParams& P = sw.T[fl >> FLAG_TYPE_SHIFT];
+    double            thrust = 0.0;  // allocation * rpm^2 with the motor speeds as they are (multirotor_model.hpp:332-335)
+    for (int m = 0; m < P.n_motors; m++) {
+      const double r = sw.S[(size_t)(F_RPM + m) * np + i];
+      thrust += P.alloc[3 * MRS_MAXM + m] * (r * r);
+    }
+    const bool   takeoff = (fl & FLAG_TAKEOFF) != 0u;
+    const double init_z  = takeoff ? sw.S[(size_t)F_INITZ * np + i] : 0.0;
+    const bool   usable  = mrs_pos_usable(y[0], y[1], y[2]);
+    if (usable && mrs_may_leave(y, 0.0, thrust, cnt, rebounce, pred_hdt, pred_lim, P.pred_a0, P.pred_thr, P.pred_drag, P.ground_enabled, P.ground_z, takeoff, init_z))
+      fctl[CTL_PRED] = 1u;  // (same value from every lane that finds one)
+  }
   bool           exported = false;
   for (uint32_t k = 0; k < cnt; k++) {
     const uint32_t g = nbr[(size_t)k * (size_t)n + (size_t)i];
@@ -1106,16 +1125,28 @@ __global__ void k_export_mark(SwarmDev sw, Pos4* pos_now, long long n_max, int r
   if (exported) atomicOr(&blk_class[i >> 6], MRS_BLK_BOUNDARY);  // the block is stepped by the boundary launch of a split tick
 }
 
-// the boundary blocks in a list (any order), their number in the control word the host reads with the export counts
-// ... and the head of the rank's slot map (export count — final: the marking launch is complete —, lanes over the list capacity)
-__global__ void k_class_list(int n_blocks, const uint32_t* blk_class, uint32_t* blk_list, uint32_t* fctl, uint32_t* map, const uint32_t* ctl) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) {
-    map[0] = fctl[CTL_EXPORTS];
+// Behind the marking launch (its block classes are complete): the boundary blocks in a list (any order) and their number; the interior
+// blocks that list a UAV of a boundary block (MRS_BLK_LAYER1: they wait for that block's epoch word in a split tick) and their number
+// (CTL_NL1: the residency bound of the split form); the head of the rank's slot map — export count (final), bit 31: some own UAV may
+// leave its skin within the horizon; lanes over the list capacity.  One thread per own UAV; list entries are still global record slots.
+__global__ void k_class_list(int n, long long n_max, int rank, const uint32_t* nbr, const uint32_t* nbr_cnt, uint32_t* blk_class, uint32_t* blk_list,
+                             uint32_t* fctl, uint32_t* map, const uint32_t* ctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    map[0] = fctl[CTL_EXPORTS] | (fctl[CTL_PRED] ? 0x80000000u : 0u);
     map[1] = ctl[6];  // lanes over the list capacity (cumulative, collide.hip k_query)
   }
-  if (b >= n_blocks) return;
-  if (blk_class[b] & MRS_BLK_BOUNDARY) blk_list[atomicAdd(&fctl[CTL_NBND], 1u)] = (uint32_t)b;
+  if (i >= n) return;
+  const uint32_t mine = blk_class[i >> 6];
+  if ((i & 63) == 0 && (mine & MRS_BLK_BOUNDARY)) blk_list[atomicAdd(&fctl[CTL_NBND], 1u)] = (uint32_t)(i >> 6);
+  if (mine & MRS_BLK_BOUNDARY) return;
+  const uint32_t cnt = nbr_cnt[i];
+  bool           l1  = false;
+  for (uint32_t k = 0; k < cnt; k++) {
+    const long long g = (long long)nbr[(size_t)k * (size_t)n + (size_t)i], q = g / n_max;
+    if (q == (long long)rank && (blk_class[(g - q * n_max) >> 6] & MRS_BLK_BOUNDARY)) l1 = true;
+  }
+  if (l1 && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
 }
 
 // start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet
@@ -1131,18 +1162,16 @@ __global__ void k_export_header(uint32_t* map, const uint32_t* fctl, const uint3
 }
 
 __global__ void k_export_translate(int n, long long n_max, int rank, long long map_stride, int block, uint32_t* nbr, const uint32_t* nbr_cnt,
-                                   const uint32_t* maps, const PosRecord* rec_all, Pos4* x_recv, PartnerConst* x_const, uint32_t* fctl, uint32_t* blk_class) {
+                                   const uint32_t* maps, const PosRecord* rec_all, Pos4* x_recv, PartnerConst* x_const, uint32_t* fctl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t cnt = nbr_cnt[i];
-  bool           l1  = false;  // this UAV lists a UAV of a boundary block (the classes of the marking launch are complete)
   for (uint32_t k = 0; k < cnt; k++) {
     const size_t    at = (size_t)k * (size_t)n + (size_t)i;
     const uint32_t  g  = nbr[at];
     const long long q  = (long long)g / n_max, j = (long long)g - q * n_max;
     if (q == (long long)rank) {
       nbr[at] = (uint32_t)j;
-      if (blk_class[j >> 6] & MRS_BLK_BOUNDARY) l1 = true;
       continue;
     }
     const uint32_t e = maps[(size_t)q * (size_t)map_stride + 2 + (size_t)j];
@@ -1159,9 +1188,6 @@ __global__ void k_export_translate(int n, long long n_max, int rank, long long m
     x_recv[slot]  = pp;
     x_const[slot] = cc;
   }
-  // interior blocks that list a UAV of a boundary block wait for that block's epoch word in a split tick (MRS_BLK_LAYER1); their
-  // number goes to the host with the first fused launch after the search (CTL_NL1: the residency bound of the split form)
-  if (l1 && !(blk_class[i >> 6] & MRS_BLK_BOUNDARY) && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
 }
 
 // handleCollisions of the tick after the most recent step, evaluated on its own from the lists (local partners: position records,
@@ -1422,7 +1448,10 @@ __global__ void k_heads_to_host(const uint32_t* maps, long long stride, int worl
     __hip_atomic_store(&host[2 * q], maps[(size_t)q * (size_t)stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&host[2 * q + 1], maps[(size_t)q * (size_t)stride + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (q == 0) __hip_atomic_store(&host[2 * world], fctl[CTL_NBND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (q == 0) {
+    __hip_atomic_store(&host[2 * world], fctl[CTL_NBND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host[2 * world + 1], fctl[CTL_NL1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 }  // namespace
 // what the host needs of a search — every rank's export count and overflow counter, this rank's boundary-block count — in pinned host
@@ -1440,7 +1469,6 @@ extern "C" const uint32_t* mrs_collide_host_heads(const CollideWork* w) { return
 extern "C" void mrs_collide_host_words_reset(CollideWork* w) {
   if (!w || !w->hostw) return;
   w->hostw[CTL_STALL] = w->hostw[CTL_PROGRESS] = w->hostw[CTL_WARN] = w->hostw[CTL_STALL2] = w->hostw[CTL_WARN2] = 0u;
-  w->hostw[CTL_NL1] = 0xFFFFFFFFu;  // "not known yet": k_layer1_to_host writes the count at the end of the search
 }
 extern "C" long long mrs_collide_export_capacity(const CollideWork* w) { return w ? w->x_cap : 0; }
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w) { return w ? w->fctl : nullptr; }
@@ -1448,7 +1476,9 @@ extern "C" void*     mrs_collide_export_send(const CollideWork* w) { return w ? 
 extern "C" void*     mrs_collide_export_recv(const CollideWork* w) { return w ? (void*)w->x_recv : nullptr; }
 
 // after a search over gathered records: mark the export set, write this rank's slot map (2 + n_max words) for the all-gather
-extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, hipStream_t st) {
+// pred_hdt >= 0: also the displacement bound over that time on the state the search found (k_export_mark)
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, double pred_hdt,
+                                              double rebounce, hipStream_t st) {
   // (the host mirrors of the control words are reset by the host once it has read what the old segment left in them: mrs_collide_host_words_reset)
   const long long n_xvec = (long long)(sizeof(Pos4) * ((size_t)w->x_cap + 1) * (size_t)(1 + 2 * w->x_world) / sizeof(uint4));
   long long       grid   = (map_words + 255) / 256;
@@ -1456,10 +1486,11 @@ extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long 
   hipLaunchKernelGGL(k_search_reset, dim3((unsigned)grid), dim3(256), 0, st, w->fctl, map_send, map_words, w->blk_class, (sw.n + 63) / 64, (uint4*)w->x_send, n_xvec);
   if (sw.n > 0) {
     const int n_blocks = (sw.n + 63) / 64;
+    (void)n_blocks;
     hipLaunchKernelGGL(k_export_mark, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw, w->P[w->pcur], n_max, rank, w->nbr, w->nbr_cnt, w->exp_slot, map_send,
-                       w->fctl, w->blk_class);
-    hipLaunchKernelGGL(k_class_list, dim3((n_blocks + 255) / 256), dim3(256), 0, st, n_blocks, w->blk_class, w->blk_list, w->fctl, map_send,
-                       w->ctl ? w->ctl : w->fctl);
+                       w->fctl, w->blk_class, pred_hdt, 0.5 * SKIN2 * (1.0 - 1e-9), rebounce);
+    hipLaunchKernelGGL(k_class_list, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, w->nbr, w->nbr_cnt, w->blk_class, w->blk_list, w->fctl,
+                       map_send, w->ctl ? w->ctl : w->fctl);
   } else {
     hipLaunchKernelGGL(k_export_header, dim3(1), dim3(1), 0, st, map_send, w->fctl, w->ctl ? w->ctl : w->fctl);  // (never searched: word 6 of fctl is 0)
   }
@@ -1471,7 +1502,7 @@ extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, 
                                                    const PosRecord* rec_all, hipStream_t st) {
   if (sw.n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_export_translate, dim3((sw.n + 255) / 256), dim3(256), 0, st, sw.n, n_max, rank, map_stride, (int)(w->x_cap + 1), w->nbr, w->nbr_cnt,
-                     maps, rec_all, w->x_recv, w->x_const, w->fctl, w->blk_class);
+                     maps, rec_all, w->x_recv, w->x_const, w->fctl);
   return hipGetLastError();
 }
 

@@ -58,7 +58,8 @@ extern "C" const uint32_t* mrs_collide_host_heads(const CollideWork* w);
 extern "C" void       mrs_collide_host_words_reset(CollideWork* w);
 extern "C" void*      mrs_collide_export_send(const CollideWork* w);
 extern "C" void*      mrs_collide_export_recv(const CollideWork* w);
-extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, hipStream_t st);
+extern "C" hipError_t mrs_collide_export_mark(SwarmDev sw, CollideWork* w, long long n_max, long long map_words, int rank, uint32_t* map_send, double pred_hdt,
+                                              double rebounce, hipStream_t st);
 extern "C" hipError_t mrs_collide_export_translate(SwarmDev sw, CollideWork* w, long long n_max, long long map_stride, int rank, const uint32_t* maps,
                                                    const PosRecord* rec_all, hipStream_t st);
 extern "C" hipError_t mrs_collide_export_dev(const SwarmDev* sw, CollideWork* w, long long my_offset, unsigned tau, int eval, int crash, double rebounce,
@@ -198,6 +199,7 @@ struct mrs_swarm {
   int       split_min_blocks = 512; // tuning / tests: MRS_SHARD_SPLIT_MIN_BLOCKS
   double    split_max_fraction = 0.25;  // ... and MRS_SHARD_SPLIT_MAX_FRACTION: the boundary launch may cover at most this share of the blocks
   uint32_t  x_nbnd = 0;             // boundary blocks of this rank as of the last search
+  uint32_t  x_nl1 = 0xFFFFFFFFu;    // ... and its interior blocks that list a UAV of a boundary block (0xFFFFFFFF: no search yet)
   double    x_dt = -1.0;            // dt of the previous call: the announcements of its last launches assumed it
   int       resident_waves = 2048;  // wave slots of the device at the interior kernel's occupancy (2 per SIMD): see split_ok()
   int64_t   x_split_ticks = 0;

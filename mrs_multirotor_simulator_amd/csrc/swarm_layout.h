@@ -130,7 +130,8 @@ enum {
                      // bits 8-9: the same, reported by SOME rank of the sharded swarm (folded from the export headers, MRS_HDR_ERROR)
   CTL_I_STARTED = 9, // tick index of the last interior launch that has started (so the interior launch before it is complete)
   CTL_NBND = 11,     // 64-UAV blocks of this rank that hold a boundary UAV (set by the search)
-  CTL_NL1 = 12,      // interior blocks that list a UAV of a boundary block (MRS_BLK_LAYER1; set by the search, mirrored to the host words)
+  CTL_NL1 = 12,      // interior blocks that list a UAV of a boundary block (MRS_BLK_LAYER1; set by the search, sent to the host with its head words)
+  CTL_PRED = 13,     // set by the search when some own UAV may leave its skin within MRS_PRED_HORIZON steps (the ticks after the search are then serial)
   CTL_WORDS = 16
 };
 // class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)

@@ -184,7 +184,8 @@ int full_gather_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Col
 // incomplete (a UAV with more neighbours than its list holds, on any rank): the caller stays on the full exchange for a while.
 // first half: everything up to the point where the host needs numbers of its own — ENQUEUED only (no host wait), so that a search
 // that is certain can follow the last launches of a segment in stream order and the segment's one synchronisation serves both
-int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c) {
+// dt: the step of the ticks that follow (the search also runs the displacement bound over MRS_PRED_HORIZON of them, split protocol only)
+int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c, double dt) {
   const int     world = s->comm_world, rank = s->comm_rank;
   const int64_t n_max = s->comm_n_max, n_rec = n_max * world, stride = map_stride(s);
   int           rc;
@@ -198,7 +199,8 @@ int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c) {
     HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
   const long long cap = mrs_collide_export_capacity(s->cwork);
   HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, /*zero=*/0, s->stream));  // (zeroed by the marking launches)
-  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, stride, rank, s->x_map_send, s->stream));
+  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, stride, rank, s->x_map_send, s->shard_split ? (double)MRS_PRED_HORIZON * dt : -1.0, c.rebounce,
+                                 s->stream));
   if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
   // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
   const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch; valid once the stream has been synchronised)
@@ -207,7 +209,9 @@ int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c) {
 }
 
 // second half, behind a synchronisation of the stream: capacities, then the lists go into export form
-int export_search_finish(mrs_swarm* s, int* incomplete) {
+// may_leave: some UAV of some rank may leave its skin within MRS_PRED_HORIZON steps of the state the search ran on (or the bound was
+// not evaluated): the ticks that follow take the serial form until the launches' own announcements cover the horizon
+int export_search_finish(mrs_swarm* s, int* incomplete, bool* may_leave) {
   const int       world = s->comm_world, rank = s->comm_rank;
   const int64_t   n_max = s->comm_n_max;
   const uint32_t* heads = mrs_collide_host_heads(s->cwork);
@@ -216,13 +220,16 @@ int export_search_finish(mrs_swarm* s, int* incomplete) {
   mrs_collide_host_words_reset(s->cwork);  // launch indices restart at 1: the host mirrors of the old segment's words are void
   const long long cap = mrs_collide_export_capacity(s->cwork);
   s->x_nbnd = s->n > 0 ? heads[2 * world] : 0u;
+  s->x_nl1  = s->n > 0 ? heads[2 * world + 1] : 0u;
+  *may_leave = !s->shard_split;
   long long need = 0;
   for (int q = 0; q < world; q++) {
-    if ((long long)heads[(size_t)q * 2] > need) need = heads[(size_t)q * 2];
+    if (heads[(size_t)q * 2] & 0x80000000u) *may_leave = true;
+    if ((long long)(heads[(size_t)q * 2] & 0x7FFFFFFFu) > need) need = heads[(size_t)q * 2] & 0x7FFFFFFFu;
     if (heads[(size_t)q * 2 + 1] != s->x_last_overflow[(size_t)q]) *incomplete = 1;
     s->x_last_overflow[(size_t)q] = heads[(size_t)q * 2 + 1];
   }
-  s->x_export_count = heads[(size_t)rank * 2];
+  s->x_export_count = heads[(size_t)rank * 2] & 0x7FFFFFFFu;
   if (*incomplete) {
     mrs_collide_invalidate_gathered(s->cwork);
     return MRS_OK;
@@ -238,11 +245,11 @@ int export_search_finish(mrs_swarm* s, int* incomplete) {
   return MRS_OK;
 }
 
-int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, int* incomplete) {
-  int rc = export_search_enqueue(s, c);
+int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, int* incomplete, bool* may_leave) {
+  int rc = export_search_enqueue(s, c, dt);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(s->stream));
-  return export_search_finish(s, incomplete);
+  return export_search_finish(s, incomplete, may_leave);
 }
 
 int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval) {
@@ -333,8 +340,8 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     // waves could fill the device, a boundary launch queued behind a late collective would find no slot and the tick would end in the
     // 10-s give-up.  So a rank stays in the serial form unless the spinners leave at least half of the wave slots (at the interior
     // kernel's two waves per SIMD) to everybody else — unless the boundary chain owns compute units of its own (MRS_SPLIT_CU_RESERVE).
-    // The count comes from the search (CTL_NL1, mirrored to the host words by its last launch); unknown yet: serial.
-    return mrs_protocol::split_residency_ok(hw ? hw[CTL_NL1] : 0xFFFFFFFFu, s->x_nbnd, s->resident_waves, s->cu_reserve);
+    // The count comes from the search (CTL_NL1, read with its head words).
+    return mrs_protocol::split_residency_ok(s->x_nl1, s->x_nbnd, s->resident_waves, s->cu_reserve);
   };
   while (done < n_ticks) {
     if (s->x_fallback_left > 0) {
@@ -346,13 +353,15 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     }
     if (!s->x_ok) {  // no usable export lists (first tick, lists gone stale): this tick on the search path
       if (s->n > 0 && (rc = launch_step(s, dt, 1))) return rc;
-      int incomplete = 0;
-      if ((rc = export_search(s, c, &incomplete))) return rc;
+      int  incomplete = 0;
+      bool may_leave  = true;
+      if ((rc = export_search(s, c, dt, &incomplete, &may_leave))) return rc;
       s->collision_ticks++;
       s->x_ticks++;
       done++;
       pending = false;
-      serial_left = (int)MRS_PRED_HORIZON;
+      // (the very first ticks of a call stay serial whatever the search says: the host may have written state since the last call)
+      if (may_leave || serial_left > 0) serial_left = (int)MRS_PRED_HORIZON;
       if (incomplete) s->x_fallback_left = 64;
       continue;
     }
@@ -425,7 +434,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     // turned into no-ops, which is the state the search belongs on either way.
     const unsigned launched = s->tau + 1 - first;
     const bool     early_search = s->early_search && mrs_protocol::search_due(stall_word(hw), warn_word(hw), done + (int)launched < n_ticks);
-    if (early_search && (rc = export_search_enqueue(s, c))) return rc;
+    if (early_search && (rc = export_search_enqueue(s, c, dt))) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     const unsigned T = stall_word(hw), W = warn_word(hw);  // identical on every rank
     const unsigned ran = mrs_protocol::ticks_ran(T, first, launched);
@@ -437,14 +446,17 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     if (mrs_protocol::search_due(T, W, done < n_ticks)) {
       // the lists are stale after step T / about to be: all ranks search on the state they have now, which also evaluates the
       // collision tick that followed the last step that ran
-      int incomplete = 0;
+      int  incomplete = 0;
+      bool may_leave  = true;
       if (early_search) {
-        if ((rc = export_search_finish(s, &incomplete))) return rc;
-      } else if ((rc = export_search(s, c, &incomplete))) {
+        if ((rc = export_search_finish(s, &incomplete, &may_leave))) return rc;
+      } else if ((rc = export_search(s, c, dt, &incomplete, &may_leave))) {
         return rc;
       }
       pending = false;
-      serial_left = (int)MRS_PRED_HORIZON;
+      // the search ran the displacement bound on the very state the next launches start from: nobody can leave its skin within the
+      // horizon -> no stall index <= MRS_PRED_HORIZON can exist, the split form may start with the first tick after the search
+      serial_left = may_leave ? (int)MRS_PRED_HORIZON : 0;
       if (incomplete) s->x_fallback_left = 64;
     }
   }
