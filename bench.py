@@ -354,13 +354,14 @@ def mean_search_candidates(x, inv_cell):
     return float(total.mean() - 1.0)  # (minus the UAV itself)
 
 
-def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"), min_ms=None, seed=3, airframe="x500", arith=None):
+def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"), min_ms=None, seed=3, airframe="x500", arith=None, substeps=None):
     """One timed workload on this rank's GPU: `n` UAVs of one airframe, regions of exactly `steps` steps (ticks).  Returns (record, st,
     cmd); the record is built on rank 0 only."""
     import mrs_multirotor_simulator_amd as M
     from mrs_multirotor_simulator_amd import airframes
     torch = R.torch
     arith = args.arith if arith is None else arith
+    substeps = args.substeps if substeps is None else substeps
     n_motors = airframes.AIRFRAMES[airframe]["n_motors"]
     st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav, n_motors=n_motors)
     sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if arith == "fast" else M.ARITH_LITERAL)
@@ -376,7 +377,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
         if coll:
             sw.tick_n(DT, k, True, False, 100.0)
         else:
-            sw.step_n(DT, k, args.substeps)
+            sw.step_n(DT, k, substeps)
 
     def sync_local():
         sw.synchronize()
@@ -415,10 +416,10 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                 sys.stderr.write(f"bench.py: live PMC traffic unavailable for {n} UAVs / {workload} ({tr_src}); using the committed profile\n")
             tr, tr_src = pmc_traffic(args, n, workload)
         npad = (n + 63) // 64 * 64
-        kernel_name = kernel_name_of(n, workload, arith, args.substeps)
+        kernel_name = kernel_name_of(n, workload, arith, substeps)
         # tick_single.hip issues a run of steps without collisions as two half-swarm launches per step on two streams
         launches_per_step = 1
-        if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-steps // args.substeps) >= 4:
+        if not coll and os.environ.get("MRS_SPLIT_STREAMS", "1") != "0" and npad // 64 >= 1024 and -(-steps // substeps) >= 4:
             launches_per_step = 2
         if tr is not None:
             tr *= launches_per_step  # the PMC figure is per dispatch; `achieved` and `traffic` are both per step
@@ -443,7 +444,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                       "median region by time.perf_counter() (wall clock: host start-up and synchronize latency of the region included), MAX over "
                       "ranks; device_ms_per_step / value_device_time = the same regions by a hipEvent pair around the region's launches",
             "config": {"workload": wl, "uavs_per_gpu": n, "airframe": airframe, "n_motors": n_motors, "arith": arith,
-                       "substeps_per_launch": args.substeps, "parallelism": f"{world} independent shard(s), no collective on the data path"},
+                       "substeps_per_launch": substeps, "parallelism": f"{world} independent shard(s), no collective on the data path"},
             # `peak` is the HBM3E spec figure in every regime (comparable across sizes); while the touched state fits the 256 MiB Infinity
             # Cache the operative limit is that cache, not HBM: `bound` says so, and the guide's measured lower bound for it is given
             "roofline": {"bound": "infinity-cache" if resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -675,6 +676,10 @@ def main():
         if R.rank == 0 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, st2, cmd2, workload="config2", uavs=400, airframe="f550", seconds=min(args.cpu_seconds, 4.0))
         out["config2"] = sub_record(rec)
+        # the same swarm with ten makeStep rounds per launch (mrs_swarm_step_n's substeps_per_launch: state kept in registers across the
+        # rounds — legal while commands are constant and collisions are off, results identical); no roofline credit for the fusion
+        rec, _, _ = step_leg(args, R, 400, "config2", 2000, 200, min_ms=30.0, airframe="f550", substeps=10)
+        out["config2"]["fused_10_substeps_per_launch"] = {k: rec[k] for k in ("value", "ms_per_step", "device_ms_per_step")}
         out["sharded_rank_standin"] = sharded_rank_record(args)
 
     import threading

@@ -13,7 +13,7 @@ for stop in (1, 3, 0):
                            os.path.join(CSRC, "collide.hip"), "-o", o])
     lib = f"/tmp/abl/lib_{stop}.so"
     subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, o] + [os.path.join(OBJ, f) for f in
-                          ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "swarm_host.o")])
+                          ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "host_api.o", "tick_single.o", "tick_sharded.o", "transport_rccl.o", "transport_local.o", "transport_peer.o")])
     env = dict(os.environ, MRS_SWARM_LIB=lib, TMPDIR="/tmp")
     d = f"/tmp/abl/prof_{stop}"
     subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),

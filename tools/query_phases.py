@@ -13,7 +13,7 @@ subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c
                        os.path.join(CSRC, "collide.hip"), "-o", o])
 lib = "/tmp/qph/libmrs_swarm_clock.so"
 subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, o] + [os.path.join(OBJ, f) for f in
-                      ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "swarm_host.o")])
+                      ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "host_api.o", "tick_single.o", "tick_sharded.o", "transport_rccl.o", "transport_local.o", "transport_peer.o")])
 os.environ["MRS_SWARM_LIB"] = lib
 LISTS = os.environ.get("QPH_LISTS", "0") == "1"  # time the list-building search (a host write before each call forces it)
 os.environ["MRS_NEIGHBOUR_LISTS"] = "1" if LISTS else "0"

@@ -58,7 +58,7 @@ def main():
             objs.append(o)
         lib = os.path.join(out_dir, f"libmrs_{name}.so")
         subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs +
-                              [os.path.join(OBJ, "collide.o"), os.path.join(OBJ, "outputs.o"), os.path.join(OBJ, "swarm_host.o")])
+                              [os.path.join(OBJ, "collide.o"), os.path.join(OBJ, "outputs.o"), *[os.path.join(OBJ, o) for o in ("host_api.o", "tick_single.o", "tick_sharded.o", "transport_rccl.o", "transport_local.o", "transport_peer.o")]])
         for arith in args.arith.split(","):
             env = dict(os.environ, MRS_SWARM_LIB=lib)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", "50",
