@@ -149,6 +149,10 @@ def parse():
     ap.add_argument("--config5-transport", choices=["rccl", "peer"], default="rccl",
                     help="collective backend of the config-5 leg: RCCL all-gather, or the library's peer-window exchange (direct writes into the "
                          "peers' device memory over xGMI, IPC handles carried by torch.distributed; never run across devices yet: opt-in)")
+    ap.add_argument("--config5-peer", choices=["auto", "on", "off"], default="auto",
+                    help="a second, GUARDED config-5 record with the peer-window exchange (`config5_peer`), run in child processes after the RCCL leg so "
+                         "that whatever happens to it cannot touch the line's other records or the exit status; auto = whenever N > 1")
+    ap.add_argument("--only-config5", action="store_true", help=argparse.SUPPRESS)  # the child run behind config5_peer: that leg alone, one JSON object
     ap.add_argument("--config5-exchange", choices=["export", "full"], default="export",
                     help="export: boundary UAVs only between two searches; full: all 48-B records on every tick")
     return ap.parse_args()
@@ -634,6 +638,37 @@ def config5_leg(args, R):
     return out if R.rank == 0 else None
 
 
+def peer_leg_in_children(args):
+    """BASELINE configs[4] once more with the peer-window exchange (direct writes into the peers' device memory, no collective library in
+    the tick) — in CHILD processes of rank 0, after the run's own process group is gone: the exchange has never run across devices, and
+    a fault there must cost this record only.  Returns the child's config-5 record, or {"error": ...}."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--only-config5", "--config5-transport", "peer",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--arith", args.arith, "--config5-uavs", str(args.config5_uavs),
+           "--config5-shards", args.config5_shards, "--config5-exchange", args.config5_exchange, "--volume-per-uav", str(args.volume_per_uav),
+           "--min-measure-ms", str(args.min_measure_ms)]
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+            "MASTER_ADDR", "MASTER_PORT")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.config5_timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {args.config5_timeout:.0f} s (child processes killed)", "transport": "peer"}
+    except OSError as e:
+        return {"error": f"{type(e).__name__}: {e}", "transport": "peer"}
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": f"child run ended with status {r.returncode} and no record: {r.stderr[-300:]}", "transport": "peer"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -642,6 +677,17 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.only_config5:  # (the child run of peer_leg_in_children: one leg, one JSON object)
+        R = Ranks()
+        try:
+            c5 = config5_leg(args, R)
+        except Exception as e:  # noqa: BLE001 - the parent records it
+            c5 = {"error": f"{type(e).__name__}: {e}", "transport": args.config5_transport}
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        if R.rank == 0:
+            print(json.dumps(c5), flush=True)
+        os._exit(0 if (c5 is None or "error" not in c5) else 3)  # (no waiting for ranks that may be stuck in a collective)
     subs = args.sub_records == "on" or (args.sub_records == "auto" and args.gpus == 1 and args.workload == "actuator"
                                         and args.uavs == 100_000 and args.substeps == 1 and not args.pmc_child)
     # roofline.traffic: the rocprofv3 --pmc child runs come FIRST, while this process has not initialised the GPU (children of a
@@ -722,10 +768,19 @@ def main():
         except Exception as e:  # noqa: BLE001 - recorded in the line, the other ranks run into their own timeout
             give_up(f"{type(e).__name__}: {e}")
         watchdog.cancel()
-        if not emit({"config5": c5}):  # the watchdog fired between the leg's return and cancel(): its line (and exit status) stand
+        extra = {"config5": c5}
+        peer = args.config5_peer == "on" or (args.config5_peer == "auto" and R.world > 1 and args.config5_transport == "rccl")
+        if peer:
+            # the run's own process group ends first (every rank's RCCL result is in hand); the guarded leg then runs in children of rank 0
+            # and can only add a record — a failure there is written into it and changes neither the other records nor the exit status
+            R.close()
+            if R.rank == 0:
+                extra["config5_peer"] = peer_leg_in_children(args)
+        if not emit(extra):  # the watchdog fired between the leg's return and cancel(): its line (and exit status) stand
             time.sleep(60)
             os._exit(3)
-        R.close()
+        if not peer:
+            R.close()
         return
     R.close()
     emit()

@@ -59,3 +59,17 @@ def test_no_cpu_fallback_for_the_hot_path():
     r = _run("--steps", "1", "--warmup", "0", "--traffic", "off", "--no-cpu-baseline")
     assert r.returncode != 0 and "no CPU fallback" in r.stderr, r.stderr[-400:]
     assert r.stdout.strip() == ""
+
+
+def test_guarded_peer_record_turns_a_failed_child_run_into_a_record():
+    """bench.py's `config5_peer` leg runs in child processes of rank 0; whatever happens to them (here: no GPU at all) becomes an
+    {"error": ...} record, never an exception or an exit status of the parent run"""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the child run would succeed")
+    import bench
+    sys.argv = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "0", "--config5-timeout", "200"]
+    args = bench.parse()
+    rec = bench.peer_leg_in_children(args)
+    assert "error" in rec and rec.get("transport") == "peer", rec
