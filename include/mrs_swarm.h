@@ -383,6 +383,14 @@ int mrs_swarm_debug_component(mrs_swarm_t* s, int32_t component, int32_t first, 
  * handleCollisions(true, crash, rebounce) on the current positions. */
 int mrs_swarm_debug_search_ms(mrs_swarm_t* s, int32_t reps, int32_t crash, double rebounce, double* avg_ms);
 
+/* test hook: ONE forced neighbour search on the current positions (it latches the forces / crash flags of
+ * handleCollisions(true, crash, rebounce)), then the lists it built: count[i] = listed neighbours of UAV i (0 for every UAV when some
+ * list came out incomplete), nbr[r * n + i] = the r-th of them in ascending index, r < min(count[i], *list_cap); rows >= count[i]
+ * hold stale values.  `nbr` holds list_cap_in rows of n entries; *list_cap returns the library's list capacity.  What the lists must
+ * hold (a superset of nanoflann's radiusSearch(3.0) result, src/multirotor_simulator.cpp:326): every UAV closer than sqrt(3) + skin. */
+int mrs_swarm_debug_neighbour_lists(mrs_swarm_t* s, int32_t crash, double rebounce, uint32_t* count, uint32_t* nbr, int32_t list_cap_in, int32_t* list_cap,
+                                    double* list_radius);
+
 /* timing helper: average device time (ms) per step-kernel launch of the last mrs_swarm_step_n / mrs_swarm_tick_n call,
  * measured with hipEvents on the swarm's stream.  mode 1: one event pair around the whole region (elapsed / launches,
  * inter-launch gaps included, no perturbation); mode 2: one pair around every launch (perturbs the region); 0: off */

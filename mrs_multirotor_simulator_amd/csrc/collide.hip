@@ -135,6 +135,79 @@ __device__ __forceinline__ void insert_uav(long long j, const Cell& c, uint32_t 
   if ((uint32_t)old != 0u) atomicOr(slot, (unsigned long long)CHAIN_BIT << 32);
 }
 
+// ---- entry format of the LIST-BUILDING searches (LISTS = 1, 2; the plain search above keeps the format above) ----
+//   x = (UAV index + 1) in the low `ib` bits (2^ib > n_total) | the top 32 - ib bits of the cell tag
+//   y = the UAV's position INSIDE its cell in 1/1024 of the cell edge, 10 bits per axis | CHAIN (bit 31)
+// A prober decides from the entry alone whether the member can be within the list radius (integer arithmetic on cell offsets and
+// the 10-bit coordinates, a bound that errs on the safe side by the quantisation step), and fetches the 48-B record only of those
+// that can: 0.7 record fetches per UAV at 64 m^3 per UAV instead of one per member of every probed cell (4.4).
+constexpr uint32_t QBITS = 10, QONE = 1u << QBITS, QMASK = QONE - 1u;
+
+template <int WIDE>  // 1: list cells of one GPU, 2: list cells of a sharded swarm.  Same cell as cell_of<WIDE>; q = 0 for unusable positions
+__device__ __forceinline__ Cell cell_q(double x, double y, double z, uint32_t& q) {
+  constexpr double ic = WIDE == 2 ? INV_CELL_WIDE2 : INV_CELL_WIDE;
+  Cell c;
+  c.ok = (fabs(x) < POS_LIMIT) && (fabs(y) < POS_LIMIT) && (fabs(z) < POS_LIMIT);  // false for NaN/inf
+  const double tx = x * ic, ty = y * ic, tz = z * ic;
+  const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+  c.x = c.ok ? (int)fx : 0;
+  c.y = c.ok ? (int)fy : 0;
+  c.z = c.ok ? (int)fz : 0;
+  // t - floor(t) is in [0, 1] — it ROUNDS to 1 for a tiny negative t (-1e-22 - (-1)) — so the product is clamped to the last unit
+  const int qx = min((int)((tx - fx) * (double)QONE), (int)QMASK), qy = min((int)((ty - fy) * (double)QONE), (int)QMASK),
+            qz = min((int)((tz - fz) * (double)QONE), (int)QMASK);
+  q = c.ok ? ((uint32_t)qx | ((uint32_t)qy << QBITS) | ((uint32_t)qz << (2 * QBITS))) : 0u;
+  return c;
+}
+
+// Can a member with in-cell coordinates qj, in the cell (ox, oy, oz) cells away, be within the list radius of a UAV with in-cell
+// coordinates qi?  Every coordinate difference in units is within (-1, 1) of 1024 x the true difference in cells (two floors), the
+// vector of the three errors is shorter than sqrt(3): the squared integer distance is compared with (radius in units + 1.75)^2
+// (q_near below; sqrt(LIST_R2) < sqrt(3) + SKIN + 1e-5).
+
+struct __attribute__((aligned(8))) HeadPair {  // two consecutive table entries in one 16-byte request (the table is 8-byte aligned)
+  uint32_t x, y, z, w;
+  __device__ operator uint4() const { return make_uint4(x, y, z, w); }
+};
+// hashes of the list-building format, split into a column part (cx, cy) and a cheap per-cell part: a prober computes the first once
+// per column of three cells.
+__device__ __forceinline__ uint32_t bucket_col(int cx, int cy) {  // bucket_of(cx, cy, cz, mask) == (bucket_col(cx, cy) + cz) & mask
+  uint32_t h = ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h;
+}
+__device__ __forceinline__ uint32_t tag_col(int cx, int cy) { return (uint32_t)cx * 0x9E3779B1u + (uint32_t)cy * 0x85EBCA77u; }
+__device__ __forceinline__ uint32_t tag_fin(uint32_t tcol, int cz, int ib) {  // the top 32 - ib bits of a product: every lower bit of the sum reaches them
+  return ((tcol + (uint32_t)cz * 0xC2B2AE3Du) * 0x27D4EB2Fu) >> ib;  // (one quarter-rate multiply costs less issue time than a shift-and-add mix of equal reach)
+}
+__device__ __forceinline__ uint32_t tag_bits(int cx, int cy, int cz, int ib) { return tag_fin(tag_col(cx, cy), cz, ib); }
+// the test described above, with the prober's part of the three differences precomputed (offset x 1024 - own coordinate); 24-bit multiplies
+template <int WIDE>
+__device__ __forceinline__ bool q_near(int dx, int dy, int dz, uint32_t qj) {
+  constexpr double ic  = WIDE == 2 ? INV_CELL_WIDE2 : INV_CELL_WIDE;
+  constexpr double ru  = (SQRT3_UP + (WIDE == 2 ? SKIN2 : SKIN) + 1e-5) * ic * (double)QONE + 1.75;
+  constexpr int    thr2 = (int)(ru * ru) + 1;
+  dx += (int)(qj & QMASK);
+  dy += (int)((qj >> QBITS) & QMASK);
+  dz += (int)((qj >> (2 * QBITS)) & QMASK);
+  return __mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz) <= thr2;
+}
+
+__device__ __forceinline__ void insert_uav2(long long j, const Cell& c, uint32_t q, uint32_t mask, int ib, uint2* head, uint2* next) {
+  if (!c.ok) {  // never inserted
+    next[j] = make_uint2(0u, 0u);
+    return;
+  }
+  const uint32_t b = bucket_of(c.x, c.y, c.z, mask);
+  const unsigned long long me = (unsigned long long)(((uint32_t)j + 1u) | (tag_bits(c.x, c.y, c.z, ib) << ib)) | ((unsigned long long)(q & ~CHAIN_BIT) << 32);
+  unsigned long long* slot = reinterpret_cast<unsigned long long*>(head + b);
+  const unsigned long long old = atomicExch(slot, me);
+  next[j] = make_uint2((uint32_t)old, (uint32_t)(old >> 32) & ~CHAIN_BIT);
+  if ((uint32_t)old != 0u) atomicOr(slot, (unsigned long long)CHAIN_BIT << 32);  // (see insert_uav)
+}
+
 // ctl[0], ctl[1]: "some UAV has left its skin" flags of alternating ticks (written by the step kernel), see the header
 template <int LISTS>
 __global__ void k_insert(const PosRecord* rec, long long n_total, uint32_t mask, uint2* head, uint2* next) {
@@ -253,7 +326,7 @@ __device__ __forceinline__ void list_tick(const SwarmDev& sw, const PosRecord* r
 template <int LISTS>
 __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int cur, int force,
                               int table_id, uint2* head_to_clear, uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash,
-                              double rebounce, Pos4* pos_now, const uint32_t* stall_word) {
+                              double rebounce, Pos4* pos_now, const uint32_t* stall_word, int ib) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   (void)stall_word;  // (the pass always runs in full: the two head tables are wiped alternately, a skipped pass would leave stale chains)
   if (LISTS) {
@@ -291,8 +364,12 @@ __global__ void k_pack_insert(SwarmDev sw, PosRecord* rec, uint32_t mask, uint2*
   if (LISTS) {
     const Pos4 pp = {r.x, r.y, r.z, (double)(sw.F[i] >> FLAG_TYPE_SHIFT)};
     pos_now[i]    = pp;
+    uint32_t   q;
+    const Cell c = cell_q<LISTS ? LISTS : 1>(r.x, r.y, r.z, q);
+    insert_uav2(i, c, q, mask, ib, head, next);
+  } else {
+    insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
   }
-  insert_uav(i, cell_of<LISTS>(r.x, r.y, r.z), mask, head, next);
 }
 
 // ---- neighbour lists over GATHERED records (multi-GPU ticks): every rank holds the current records of all UAVs after the
@@ -398,7 +475,7 @@ __global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, doub
 __global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRecord* rec_build, long long n_total, long long my_offset, uint32_t mask,
                                         uint2* head, uint2* next, uint32_t* ctl, int cur, int force, int table_id, uint2* head_to_clear,
                                         uint32_t table_size, const uint32_t* nbr, const uint32_t* nbr_cnt, int crash, double rebounce, const double* bb,
-                                        int own_copy_only) {
+                                        int own_copy_only, int ib) {
   const long long j  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int       ic = j < sw.n ? (int)j : sw.n - 1;
   const uint32_t  cnt = nbr_cnt[ic], j0 = nbr[ic];
@@ -419,10 +496,11 @@ __global__ void k_insert_gathered_lists(SwarmDev sw, const PosRecord* rec, PosRe
   if (j >= n_total) return;
   const PosRecord r = rec[j];
   if (!own_copy_only || (j >= my_offset && j < my_offset + sw.n)) rec_build[j] = r;  // (42 MB less to write per search at 8 x 125 k)
-  Cell            c = cell_of<2>(r.x, r.y, r.z);
+  uint32_t        q;
+  Cell            c = cell_q<2>(r.x, r.y, r.z, q);
   // outside this rank's widened bounding box: nobody here can list it (a comparison with NaN bounds — no usable own record — is false)
   c.ok = c.ok && r.x >= bb[0] && r.y >= bb[1] && r.z >= bb[2] && r.x <= bb[3] && r.y <= bb[4] && r.z <= bb[5];
-  insert_uav(j, c, mask, head, next);
+  insert_uav2(j, c, q, mask, ib, head, next);
 }
 
 // The 27 bucket heads of a UAV's neighbourhood, filtered: .x != 0 marks an entry for the work list (a head of the probed cell,
@@ -721,6 +799,313 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   }
 }
 
+// ---- the list-building query (LISTS = 1, 2) ----
+// LPU lanes per UAV share its nine probe columns, a single-wave block serves 64 / LPU UAVs.  What bounds the kernel is the number of
+// instructions its waves issue (rocprofv3 counters, MEASUREMENTS 6.6: a SIMD spent 17 of the first version's 22 us issuing), so the
+// code below is written for few of them: hashes split into a column part and a cheap per-cell part, 24-bit multiplies, one LDS
+// atomic per lane, and as many UAVs per wave as still leaves every SIMD a few waves to overlap round trips with.
+//   1  every lane fetches the bucket heads of its columns (one round trip; three consecutive buckets = two requests) and decides from
+//      the entries alone (tag, in-cell coordinates) which members can be within the list radius; those, and the heads of chained
+//      buckets, become ITEMS of the wave's LDS work list
+//   2  the work list is swept with uniform control flow, one item per lane: the member's position (exact cell, exact squared distance)
+//      and its chain link, requested together; a link that goes on is written back — compacted to the front, see sweep_window — and
+//      the shrunken list is swept again until every chain has ended.  The literal collision predicate is evaluated on the (rare) members
+//      closer than sqrt(3)
+//   3  the lanes of a UAV order its list by index and write it out; its first lane accumulates the hits of THIS tick in ascending
+//      partner index, exactly as k_query does
+constexpr uint32_t IT_VERIFY = 1u << 14, IT_WALK = 1u << 15;  // item meta (16 bits): owner | probe << 6 | flags
+
+// reference path for one UAV: see query_lane_sweeps (the same sweeps over entries of the list-building format)
+template <int WIDE>
+__device__ void query_lane_sweeps2(const PosRecord& me, const Cell& c, long long gi, const PosRecord* rec, long long n_total, uint32_t mask, int ib,
+                                   const uint2* head, const uint2* next, int crash, double rebounce, double& fx, double& fy, double& fz,
+                                   bool& crashed) {
+  const uint32_t ibm = (1u << ib) - 1u;
+  long long      prev = -1;
+  for (;;) {
+    long long best = n_total;
+    for (int q = 0; q < 27; q++) {
+      const int      cx = c.x + q / 9 - 1, cy = c.y + (q / 3) % 3 - 1, cz = c.z + q % 3 - 1;
+      const uint32_t tg = tag_bits(cx, cy, cz, ib);
+      for (uint2 e = head[bucket_of(cx, cy, cz, mask)]; e.x != 0u; e = next[(e.x & ibm) - 1u]) {
+        const long long j = (long long)(e.x & ibm) - 1;
+        if ((e.x >> ib) != tg || j <= prev || j >= best || j == gi) continue;
+        const PosRecord o  = rec[j];
+        const Cell      oc = cell_of<WIDE>(o.x, o.y, o.z);
+        if (oc.x != cx || oc.y != cy || oc.z != cz) continue;  // another cell sharing the bucket (and the tag)
+        if (qualifies(me, o, crash)) best = j;
+      }
+    }
+    if (best >= n_total) break;
+    apply_partner(me, rec[best], crash, rebounce, fx, fy, fz, crashed);
+    prev = best;
+  }
+}
+
+#ifdef MRS_Q2_CLOCK
+// 100-MHz timestamp that cannot be scheduled before `dep` is available, nor across memory operations
+__device__ __forceinline__ unsigned long long clock_dep(uint32_t dep) {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n v_readfirstlane_b32 s4, %1\n s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory", "s4");
+  return t;
+}
+#endif
+template <int LISTS, int LPU>
+__global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask, int ib,
+                                               const uint2* head, const uint2* next, int crash, double rebounce, uint32_t* ctl, int cur, int force,
+                                               uint32_t* nbr, uint32_t* nbr_cnt, uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau) {
+  constexpr int UPW    = 64 / LPU;              // UAVs per wave
+  constexpr int CPL    = (9 + LPU - 1) / LPU;   // columns (cx, cy) of three probes per lane
+  constexpr int WL_CAP = UPW * 27;              // every probe of the wave an item: the list cannot overflow
+  if (!force && ctl[cur] == 0u) return;  // list tick: the insert kernel has done the work
+#ifdef MRS_Q2_CLOCK  // timing build (tools/search_phases.py): 100-MHz stamps of the wave's phases instead of the first UAV's list
+  uint32_t ts[6];
+#define MRS_Q2_STAMP(k, dep) ts[k] = (uint32_t)clock_dep(dep)
+  MRS_Q2_STAMP(0, 0u);
+#else
+#define MRS_Q2_STAMP(k, dep)
+#endif
+  // (a search queued ahead of time behind launches that have stalled: lists as usual, no forces or crash flags — see k_query)
+  const bool muted = stall_word && *stall_word != 0u;
+  __shared__ int4      me_cell[UPW];  // cell, .w = in-cell coordinates
+  __shared__ double    me_pos[UPW][3];
+  __shared__ uint32_t  wl_j[WL_CAP + 1];  // work list: member (record index),   (+1: where the items nobody wants are written)
+  __shared__ uint16_t  wl_m[WL_CAP + 1];  //            meta
+  __shared__ uint32_t  wl_n, next_n, hit_overflow;
+  __shared__ uint32_t  nl_j[UPW][LIST_CAP], nl_n[UPW];
+  __shared__ uint32_t  hit_j[UPW][HIT_CAP], hit_n[UPW];
+
+  const int       lane = threadIdx.x, u = lane / LPU, r = lane % LPU;
+  const int       i      = blockIdx.x * UPW + u;
+  const bool      active = i < sw.n;
+  const long long gi     = my_offset + i;
+  const long long wave_first = my_offset + (long long)blockIdx.x * UPW;
+  const uint32_t  ibm    = (1u << ib) - 1u;
+  double          mx, my, mz;
+  mx = my = mz = __longlong_as_double(0x7ff8000000000000ll);
+  if (active) {
+    const double*  pm = reinterpret_cast<const double*>(rec + gi);
+    const double2 xy = *reinterpret_cast<const double2*>(pm);
+    mx = xy.x;
+    my = xy.y;
+    mz = pm[2];
+  }
+  uint32_t   qme;
+  const Cell c = cell_q<LISTS>(mx, my, mz, qme);
+  MRS_Q2_STAMP(1, qme);
+  if (r == 0) {
+    me_cell[u]   = make_int4(c.x, c.y, c.z, (int)qme);
+    me_pos[u][0] = mx;
+    me_pos[u][1] = my;
+    me_pos[u][2] = mz;
+    nl_n[u]      = 0;
+    hit_n[u]     = 0;
+  }
+  if (lane == 0) {
+    wl_n         = 0;
+    hit_overflow = 0;
+  }
+  __syncthreads();
+#if defined(MRS_Q2_STOP) && MRS_Q2_STOP == 1  // (ablation builds of tools/build_variants.sh: timing only, wrong results)
+  if (qme == 0xFFFFFFFFu) nbr_cnt[i] = 1;
+  return;
+#endif
+  // 1: bucket heads, a column (cx, cy) at a time: its three cells sit in consecutive buckets (bucket_of), so two requests — 16 B and
+  //    8 B — fetch them; the table carries one spare entry behind its end for the 16-B request of the last bucket, whose second half
+  //    is bucket 0 (fetched on its own, once in T columns).  Unconditional loads from always-valid addresses: columns beyond the ninth
+  //    repeat the lane's first.
+  {
+    uint2    e[CPL][3];
+    uint32_t tcol[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const int      cq = (r + k * LPU) < 9 ? (r + k * LPU) : r;
+      const int      cx = c.x + cq / 3 - 1, cy = c.y + cq % 3 - 1;
+      const uint32_t b0 = (bucket_col(cx, cy) + (uint32_t)(c.z - 1)) & mask;
+      tcol[k]           = tag_col(cx, cy);
+      const uint4    a  = *reinterpret_cast<const HeadPair*>(head + b0);
+      e[k][0] = make_uint2(a.x, a.y);
+      e[k][1] = make_uint2(a.z, a.w);
+      e[k][2] = head[(b0 + 2u) & mask];
+      if (b0 == mask) e[k][1] = head[0];
+    }
+    MRS_Q2_STAMP(2, e[0][0].x ^ e[CPL - 1][2].x);
+    const int qix = (int)(qme & QMASK), qiy = (int)((qme >> QBITS) & QMASK), qiz = (int)((qme >> (2 * QBITS)) & QMASK);
+    uint32_t  itj[CPL * 3], itm[CPL * 3], nit = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const int cq = r + k * LPU;
+      const int ox = (cq < 9 ? cq : r) / 3 - 1, oy = (cq < 9 ? cq : r) % 3 - 1;
+      const int dx = ox * (int)QONE - qix, dy = oy * (int)QONE - qiy;
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) {
+        const uint2    en    = e[k][dz];
+        const uint32_t j     = (en.x & ibm) - 1u;
+        const bool     match = (en.x >> ib) == tag_fin(tcol[k], c.z + dz - 1, ib) && j != (uint32_t)gi &&  // idx == i, src/multirotor_simulator.cpp:335
+                               q_near<LISTS>(dx, dy, (dz - 1) * (int)QONE - qiz, en.y);
+        const bool     chain = (en.y & CHAIN_BIT) != 0u;
+        const bool     take  = cq < 9 && c.ok && en.x != 0u && (match || chain);
+        itj[k * 3 + dz] = j;
+        itm[k * 3 + dz] = take ? ((uint32_t)u | ((uint32_t)(cq * 3 + dz) << 6) | (match ? IT_VERIFY : 0u) | (chain ? IT_WALK : 0u)) : 0u;
+        nit += take ? 1u : 0u;
+      }
+    }
+    uint32_t pos = nit ? atomicAdd(&wl_n, nit) : 0u;  // ONE atomic per lane; the items go to consecutive slots
+#pragma unroll
+    for (int t = 0; t < CPL * 3; t++) {
+      const uint32_t at = itm[t] ? pos : (uint32_t)WL_CAP;  // (branch-free: an item nobody wants goes to the spare slot)
+      wl_j[at] = itj[t];
+      wl_m[at] = (uint16_t)itm[t];
+      pos += itm[t] ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+#if defined(MRS_Q2_STOP) && MRS_Q2_STOP == 2
+  if (active && r == 0) nbr_cnt[i] = wl_n;
+  return;
+#endif
+  MRS_Q2_STAMP(3, wl_n);
+  // 2: sweeps.  An item asks for what it needs and nothing else — the position of a member to verify (24 B), the link of a chain to
+  //    walk (8 B); the other address of each lane is one the whole wave shares
+  for (uint32_t wn = wl_n; wn != 0u;) {
+    if (lane == 0) next_n = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < wn; base += 64) {
+      const uint32_t p = base + lane;
+      if (p < wn) {
+        const uint2   it = make_uint2(wl_j[p], (uint32_t)wl_m[p]);
+        const int     ow = (int)(it.y & 0x3Fu), q = (int)((it.y >> 6) & 0x1Fu);
+        const bool    ver = (it.y & IT_VERIFY) != 0u, walk = (it.y & IT_WALK) != 0u;
+        const uint2   nx = next[walk ? (long long)it.x : wave_first];
+        const double* po = reinterpret_cast<const double*>(rec + (ver ? (long long)it.x : wave_first));
+        const double2 oxy = *reinterpret_cast<const double2*>(po);
+        const double  oz_ = po[2];
+        const int     cq = q / 3, ox = cq / 3 - 1, oy = cq % 3 - 1, oz = q % 3 - 1;
+        const int4    mc = me_cell[ow];
+        if (ver) {
+          const Cell oc = cell_of<LISTS>(oxy.x, oxy.y, oz_);
+          if (oc.ok && oc.x == mc.x + ox && oc.y == mc.y + oy && oc.z == mc.z + oz) {  // (else: another cell that shares bucket and tag bits)
+            const double d0 = me_pos[ow][0] - oxy.x, d1 = me_pos[ow][1] - oxy.y, d2 = me_pos[ow][2] - oz_;
+            const double dd = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
+            if (dd < (LISTS == 2 ? LIST_R2_2 : LIST_R2)) {
+              const uint32_t k = atomicAdd(&nl_n[ow], 1u);
+              if (k < (uint32_t)LIST_CAP) nl_j[ow][k] = it.x;
+            }
+            if (dd < 3.0) {  // close enough for the collision predicate (rare): now the airframe constants of both
+              if (qualifies(rec[wave_first + ow], rec[it.x], crash)) {
+                const uint32_t k = atomicAdd(&hit_n[ow], 1u);
+                if (k < (uint32_t)HIT_CAP)
+                  hit_j[ow][k] = it.x;
+                else
+                  hit_overflow = 1;
+              }
+            }
+          }
+        }
+        if (walk && nx.x != 0u) {  // the chain goes on: its next member joins the next sweep
+          const uint32_t j     = (nx.x & ibm) - 1u;
+          const uint32_t qo    = (uint32_t)mc.w;
+          const bool     match = (nx.x >> ib) == tag_fin(tag_col(mc.x + ox, mc.y + oy), mc.z + oz, ib) && (long long)j != wave_first + ow &&
+                                 q_near<LISTS>(ox * (int)QONE - (int)(qo & QMASK), oy * (int)QONE - (int)((qo >> QBITS) & QMASK),
+                                               oz * (int)QONE - (int)((qo >> (2 * QBITS)) & QMASK), nx.y);
+          const uint32_t k = atomicAdd(&next_n, 1u);
+          wl_j[k] = j;
+          wl_m[k] = (uint16_t)((it.y & 0x7FFu) | IT_WALK | (match ? IT_VERIFY : 0u));
+        }
+      }
+    }
+    __syncthreads();
+    wn = next_n;
+    __syncthreads();  // nobody resets the counter before everybody has read it
+  }
+#if defined(MRS_Q2_STOP) && MRS_Q2_STOP == 3
+  if (active && r == 0) nbr_cnt[i] = nl_n[u] + hit_n[u];
+  return;
+#endif
+  MRS_Q2_STAMP(4, nl_n[u]);
+  // 3: forces of this tick (first lane of every UAV), lists (all its lanes)
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  bool   crashed = false;
+  if (active && r == 0 && c.ok) {
+    const uint32_t nh = hit_n[u];
+    if (nh) {
+      const PosRecord me = rec[gi];
+      if (hit_overflow && nh > (uint32_t)HIT_CAP) {  // more qualifying partners than the hit list holds: the reference path
+        query_lane_sweeps2<LISTS>(me, c, gi, rec, n_total, mask, ib, head, next, crash, rebounce, fx, fy, fz, crashed);
+      } else {
+        uint32_t prev = 0;
+        for (uint32_t h = 0; h < nh; h++) {  // selection by repeated minimum: nh <= 6, almost always 1
+          uint32_t best = 0xFFFFFFFFu;
+          for (uint32_t k = 0; k < nh; k++) {
+            const uint32_t j = hit_j[u][k];
+            if ((h == 0 || j > prev) && j < best) best = j;
+          }
+          apply_partner(me, rec[best], crash, rebounce, fx, fy, fz, crashed);
+          prev = best;
+        }
+      }
+    }
+  }
+  uint32_t cnt = nl_n[u];
+  if (cnt > (uint32_t)LIST_CAP) {  // an incomplete list keeps the next tick in rebuild mode
+    if (r == 0) {
+      ctl[cur ^ 1] = 1u;
+      atomicAdd(&ctl[6], 1u);  // statistics: UAVs over the list capacity
+      if (stall_word) {        // a search queued in stream order: the fused launches behind it must not use the incomplete lists
+        *stall_word = stall_tau;
+        __hip_atomic_store(&hostw[CTL_STALL], stall_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    cnt = 0;
+  }
+  if (active) {
+    for (uint32_t k = (uint32_t)r; k < cnt; k += LPU) {  // ascending: an entry's row is the number of smaller ones (indices are distinct)
+      const uint32_t j = nl_j[u][k];
+      uint32_t       row = 0;
+      for (uint32_t m = 0; m < cnt; m++) row += nl_j[u][m] < j ? 1u : 0u;
+      nbr[(size_t)row * sw.n + i] = j;
+    }
+    if (r == 0) nbr_cnt[i] = cnt;
+  }
+  if (active && r == 0 && !muted) {
+    sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
+    sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
+    sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
+    if (crashed) sw.F[i] |= FLAG_CRASHED;
+  }
+#ifdef MRS_Q2_CLOCK
+  MRS_Q2_STAMP(5, cnt);
+  if (lane == 0 && active) {
+    for (int k = 0; k < 6; k++) nbr[(size_t)k * sw.n + i] = ts[k];
+    nbr_cnt[i] = 6;
+  }
+#endif
+#undef MRS_Q2_STAMP
+}
+
+// lanes per UAV: four (16 UAVs per wave: 6 250 waves at 100 k UAVs, six resident per SIMD) up to 256 k UAVs — measured against two at
+// 100 k / 125 k: 36.9 / 43.1 us per search against 38.1 / 48.1 — and two beyond, where the waves come in rounds anyway (MEASUREMENTS 6.6)
+template <int LISTS>
+static void launch_query2(int lpu, SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask, int ib, const uint2* head,
+                          const uint2* next, int crash, double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt,
+                          uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau, hipStream_t st) {
+#define MRS_Q2_LAUNCH(L)                                                                                                                        \
+  hipLaunchKernelGGL((k_query2<LISTS, L>), dim3((sw.n + 64 / L - 1) / (64 / L)), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, ib, head, next, crash, \
+                     rebounce, ctl, cur, force, nbr, nbr_cnt, stall_word, hostw, stall_tau)
+  if (lpu == 1)
+    MRS_Q2_LAUNCH(1);
+  else if (lpu == 2)
+    MRS_Q2_LAUNCH(2);
+  else
+    MRS_Q2_LAUNCH(4);
+#undef MRS_Q2_LAUNCH
+}
+static int query_lpu(long long n_own) {
+  static const int forced = getenv("MRS_QUERY_LPU") ? atoi(getenv("MRS_QUERY_LPU")) : 0;  // tuning aid
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return n_own > 262144 ? 2 : 4;
+}
+
 }  // namespace
 
 struct CollideWork {
@@ -822,17 +1207,24 @@ extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** re
   *lim2 = (0.5 * SKIN) * (0.5 * SKIN) * (1.0 - 1e-9);
 }
 
+// bits of a record index + 1 in an entry of the list-building format (2^ib > n_total; the cell tag keeps the other 32 - ib)
+static inline int index_bits(long long n_total) {
+  int ib = 1;
+  while (ib < 31 && (1ll << ib) <= n_total) ib++;
+  return ib;
+}
+
 static hipError_t ensure_tables(CollideWork* w, long long n_total, hipStream_t st) {
   uint32_t T = 1024;
   while ((long long)T < MRS_TABLE_FACTOR * n_total) T <<= 1;  // load factor <= 0.25 (2x and 8x tables measured slower: more chains / more misses)
   if (n_total > w->cap_n || T > w->cap_T) {
     CK(hipStreamSynchronize(st));
     free_work(w);
-    CK(hipMalloc(&w->head[0], sizeof(uint2) * (size_t)T));
-    CK(hipMalloc(&w->head[1], sizeof(uint2) * (size_t)T));
+    CK(hipMalloc(&w->head[0], sizeof(uint2) * ((size_t)T + 1)));  // (+1: k_query2 reads two entries at a time, the spare one stays empty)
+    CK(hipMalloc(&w->head[1], sizeof(uint2) * ((size_t)T + 1)));
     CK(hipMalloc(&w->next, sizeof(uint2) * (size_t)n_total));
-    CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * (size_t)T, st));  // afterwards every query wipes the table of the next tick
-    CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * (size_t)T, st));
+    CK(hipMemsetAsync(w->head[0], 0, sizeof(uint2) * ((size_t)T + 1), st));  // afterwards every query wipes the table of the next tick
+    CK(hipMemsetAsync(w->head[1], 0, sizeof(uint2) * ((size_t)T + 1), st));
     w->cap_n = n_total;
     w->cap_T = T;
     w->cur   = 0;
@@ -877,7 +1269,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
   w->cur ^= 1;
   if (rec_is_local_scratch)
     hipLaunchKernelGGL(k_pack_insert<false>, dim3(gN), dim3(256), 0, st, sw, const_cast<PosRecord*>(rec), mask, head, w->next, nullptr, 0, 1, 0,
-                       nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr, nullptr);
+                       nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr, nullptr, 0);
   else
     hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
   hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
@@ -892,6 +1284,19 @@ extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t 
   for (int k = 0; k < 8; k++) out8[k] = 0;
   if (!w || !w->ctl) return hipSuccess;
   CK(hipMemcpyAsync(out8, w->ctl, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return hipStreamSynchronize(st);
+}
+
+extern "C" void mrs_collide_list_geometry(int* list_cap, double* list_radius) {
+  *list_cap    = LIST_CAP;
+  *list_radius = SQRT3_UP + SKIN;
+}
+// test hook: the lists of the last single-GPU search (synchronises the stream)
+extern "C" hipError_t mrs_collide_copy_lists(const CollideWork* w, long long n, uint32_t* count, uint32_t* nbr, int rows, hipStream_t st) {
+  if (!w || !w->nbr || !w->lists_live) return hipErrorInvalidValue;
+  CK(hipMemcpyAsync(count, w->nbr_cnt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+  for (int r = 0; r < rows && r < LIST_CAP; r++)  // (row r of the device array starts at r * n: the lists are stored row-major over the swarm's n)
+    CK(hipMemcpyAsync(nbr + (size_t)r * (size_t)n, w->nbr + (size_t)r * (size_t)n, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
   return hipStreamSynchronize(st);
 }
 
@@ -934,10 +1339,11 @@ extern "C" hipError_t mrs_collide_run_lists(SwarmDev sw, CollideWork** work, int
   uint2*         head = w->head[tid];
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
+  const int ib = index_bits(n);
   hipLaunchKernelGGL(k_pack_insert<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sw, w->rec_build, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur], guard_tau ? w->fctl + CTL_STALL : nullptr);
-  hipLaunchKernelGGL(k_query<1>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, w->rec_build, n, 0ll, mask, head, w->next, other, T, crash,
-                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, guard_tau ? w->fctl + CTL_STALL : nullptr, w->hostw, guard_tau);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->P[w->pcur], guard_tau ? w->fctl + CTL_STALL : nullptr, ib);
+  launch_query2<1>(query_lpu(n), sw, w->rec_build, n, 0ll, mask, ib, head, w->next, crash, rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt,
+                   guard_tau ? w->fctl + CTL_STALL : nullptr, w->hostw, guard_tau, st);
   w->fcur ^= 1;  // steps launched from now on report into the flag the next tick reads
   w->lists_live = true;
   w->g_lists_live = false;
@@ -984,6 +1390,7 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   uint2*         other = w->head[tid ^ 1];
   w->cur ^= 1;
   const unsigned gN = (unsigned)((n_total + 255) / 256);
+  const int      ib = index_bits(n_total);
   const double   lim2 = (0.5 * SKIN2) * (0.5 * SKIN2) * (1.0 - 1e-9);
   if (!w->g_bbox) CK(hipMalloc(&w->g_bbox, sizeof(double) * 6 * (BBOX_BLOCKS + 1)));  // the box, then the partial boxes
   if (force) {
@@ -996,9 +1403,9 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, rec, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, force);
   hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, force);
   hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
-                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->g_bbox, export_form ? 1 : 0);
-  hipLaunchKernelGGL(k_query<2>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
-                     rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt, tid, nullptr, nullptr, 0u);
+                     w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->g_bbox, export_form ? 1 : 0, ib);
+  launch_query2<2>(query_lpu(sw.n), sw, rec, n_total, my_offset, mask, ib, head, w->next, crash, rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt,
+                   nullptr, nullptr, 0u, st);
   w->fcur ^= 1;
   w->g_lists_live  = true;
   w->g_export_form = export_form;

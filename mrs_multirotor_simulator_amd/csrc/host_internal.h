@@ -69,6 +69,8 @@ extern "C" hipError_t mrs_collide_export_fold_stall(CollideWork* w, unsigned pro
 extern "C" hipError_t mrs_collide_fused_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void       mrs_collide_invalidate_gathered(CollideWork* w);
 extern "C" void mrs_collide_step_hook(const CollideWork* w, const PosRecord** rec, uint32_t** flag, double* lim2);
+extern "C" void       mrs_collide_list_geometry(int* list_cap, double* list_radius);
+extern "C" hipError_t mrs_collide_copy_lists(const CollideWork* w, long long n, uint32_t* count, uint32_t* nbr, int rows, hipStream_t st);
 extern "C" hipError_t mrs_collide_rebuilds(const CollideWork* w, hipStream_t st, unsigned* out);
 extern "C" hipError_t mrs_collide_debug_words(const CollideWork* w, hipStream_t st, unsigned* out8);
 extern "C" void mrs_collide_free(CollideWork* w);

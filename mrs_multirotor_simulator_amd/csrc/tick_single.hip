@@ -500,6 +500,24 @@ int mrs_swarm_tick_n(mrs_swarm_t* s, double dt, int32_t n_ticks, int32_t enabled
 // measurement hook (bench.py roofline_collision): `reps` neighbour searches of the single-GPU collision pass back to back on the
 // swarm's stream — pack + insert, then the list-building query, exactly what a tick that repeats the search launches — between
 // two hipEvents.  The forces / crash flags latched are those of handleCollisions(enabled, crash, rebounce) on the current positions.
+int mrs_swarm_debug_neighbour_lists(mrs_swarm_t* s, int32_t crash, double rebounce, uint32_t* count, uint32_t* nbr, int32_t list_cap_in, int32_t* list_cap,
+                                    double* list_radius) {
+  MRS_ENTER(s);
+  if (!s || !count || !nbr || list_cap_in < 1 || !list_cap || !list_radius) return fail(MRS_ERR_ARG, "bad neighbour-list arguments");
+  if (s->comm_world > 1 || !s->use_lists) return fail(MRS_ERR_ARG, "neighbour lists: single-GPU swarms with neighbour lists only");
+  mrs_collide_list_geometry(list_cap, list_radius);
+  if (s->n == 0) return MRS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  int rc = settle(s);
+  if (rc) return rc;
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  const mrs_swarm::Collide c{true, 1, crash, rebounce};
+  if ((rc = collide_now(s, c, /*force=*/true))) return rc;
+  s->fext_active = true;
+  HIPCHK(mrs_collide_copy_lists(s->cwork, s->n, count, nbr, list_cap_in, s->stream));
+  return MRS_OK;
+}
+
 int mrs_swarm_debug_search_ms(mrs_swarm_t* s, int32_t reps, int32_t crash, double rebounce, double* avg_ms) {
   MRS_ENTER(s);
   if (!s || reps < 1 || !avg_ms) return fail(MRS_ERR_ARG, "bad search-timing arguments");

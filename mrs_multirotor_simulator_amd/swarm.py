@@ -99,7 +99,7 @@ ABI_SYMBOLS = [
     "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
-    "mrs_swarm_debug_search_ms", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
+    "mrs_swarm_debug_search_ms", "mrs_swarm_debug_neighbour_lists", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
 ]
 
 STATE_DTYPE = np.dtype([("x", "f8", 3), ("v", "f8", 3), ("v_prev", "f8", 3), ("R", "f8", (3, 3)), ("omega", "f8", 3), ("motor_rpm", "f8", 8),
@@ -281,12 +281,15 @@ def load_library():
         "mrs_swarm_last_step_kernel_ms": [vp, dp, ip],
         "mrs_swarm_set_profiling": [vp, i32],
         "mrs_swarm_debug_search_ms": [vp, i32, i32, f64, dp],
+        "mrs_swarm_debug_neighbour_lists": [vp, i32, f64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32, C.POINTER(C.c_int32), dp],
         "mrs_swarm_clone_resized": [vp, i32, C.POINTER(vp)],
         "mrs_swarm_copy_uavs": [vp, i32, vp, i32, i32],
         "mrs_swarm_step_range": [vp, i32, i32, f64],
         "mrs_swarm_get_states": [vp, i32, i32, vp],
     }
     for name, args in sig.items():
+        if os.environ.get("MRS_SWARM_LIB") and not hasattr(L, name):
+            continue  # (an older library given for a same-box A/B measurement: the call fails when used, not the import)
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -451,6 +454,15 @@ class Swarm:
         ms = C.c_double()
         _check(_lib.mrs_swarm_debug_search_ms(self._h, int(reps), int(bool(crash)), float(rebounce), C.byref(ms)))
         return ms.value
+
+    def debug_neighbour_lists(self, crash=False, rebounce=100.0, rows=24):
+        """one forced search on the current positions -> (count[n], nbr[rows, n], list capacity, list radius): test hook"""
+        count, nbr = np.zeros(self.n, dtype=np.uint32), np.zeros((rows, self.n), dtype=np.uint32)
+        cap, radius = C.c_int32(), C.c_double()
+        u32p = C.POINTER(C.c_uint32)
+        _check(_lib.mrs_swarm_debug_neighbour_lists(self._h, int(bool(crash)), float(rebounce), count.ctypes.data_as(u32p), nbr.ctypes.data_as(u32p), int(rows),
+                                                    C.byref(cap), C.byref(radius)))
+        return count, nbr, cap.value, radius.value
 
     def set_profiling(self, enabled):
         _check(_lib.mrs_swarm_set_profiling(self._h, int(enabled)))

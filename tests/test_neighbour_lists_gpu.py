@@ -1,0 +1,96 @@
+"""The neighbour lists a search builds, read back through mrs_swarm_debug_neighbour_lists and compared with brute force.
+
+What replaces nanoflann's radiusSearch(3.0) (src/multirotor_simulator.cpp:326, include/nanoflann.hpp:273-311) between two searches
+is a list per UAV of every UAV within sqrt(3) + skin of it at search time: the lists must hold EXACTLY those (the squared distance
+is evaluated in the reference's own order, ((0 + dx^2) + dy^2) + dz^2), in ascending index, whatever the cells, bucket chains and
+tag collisions of the hash underneath look like."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def brute_lists(pos, radius2):
+    """neighbour sets by the literal metric, blockwise (n up to ~20 000)"""
+    n = len(pos)
+    out = [None] * n
+    usable = np.all(np.isfinite(pos), axis=1)
+    for lo in range(0, n, 1024):
+        hi = min(n, lo + 1024)
+        with np.errstate(invalid="ignore"):
+            d0 = pos[lo:hi, None, 0] - pos[None, :, 0]
+            d1 = pos[lo:hi, None, 1] - pos[None, :, 1]
+            d2 = pos[lo:hi, None, 2] - pos[None, :, 2]
+            near = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < radius2
+        near &= usable[None, :]
+        for i in range(lo, hi):
+            near[i - lo, i] = False
+            out[i] = np.nonzero(near[i - lo])[0] if usable[i] else np.zeros(0, dtype=np.int64)
+    return out
+
+
+def check_lists(M, pos, what):
+    n = len(pos)
+    g = M.Swarm(n, arith=M.ARITH_LITERAL)
+    g.construct(0, n, helpers.to_product_params(M, helpers.oracle_params("x500")), pos, np.zeros(n))
+    count, nbr, cap, radius = g.debug_neighbour_lists()
+    assert cap == 24 and nbr.shape == (24, n)
+    r2 = radius * radius * (1.0 + 1e-9) + 1e-5  # collide.hip LIST_R2
+    want = brute_lists(pos, r2)
+    longest = max(len(w) for w in want)
+    assert longest <= cap, f"{what}: the scenario overflows the lists ({longest} neighbours)"
+    bad = []
+    for i in range(n):
+        got = nbr[:count[i], i].astype(np.int64)
+        if len(got) != len(want[i]) or np.any(got != want[i]):
+            bad.append((i, got.tolist(), want[i].tolist()))
+    assert not bad, f"{what}: {len(bad)} of {n} lists differ, first: {bad[:3]}"
+    listed = sum(len(w) for w in want)
+    print(f"{what}: {n} UAVs, {listed / n:.2f} listed neighbours per UAV (longest list {longest}), all lists equal brute force")
+    return g
+
+
+def test_lists_of_a_random_swarm(mrs):
+    rng = np.random.default_rng(11)
+    n = 20000
+    side = (n * 30.0) ** (1 / 3)  # 30 m^3 per UAV
+    pos = rng.uniform(-side / 2, side / 2, (n, 3))  # negative coordinates: cells below zero
+    check_lists(mrs, pos, "random, 30 m^3 per UAV")
+
+
+def test_lists_of_a_dense_sheet(mrs):
+    """pairs 0.55 m apart, 1.9 m between pairs, rows 2.5 m apart: most cells hold two or three UAVs — every bucket is a chain"""
+    m = 900
+    pos = np.zeros((m, 3))
+    for i in range(m):
+        pair = i // 2
+        pos[i] = (1.9 * (pair % 30) + 0.55 * (i % 2), 2.5 * (pair // 30), 9.0 + 0.02 * (i % 5))
+    check_lists(mrs, pos, "dense sheet")
+    check_lists(mrs, pos + np.array([0.2681, -0.0313, 0.011]), "dense sheet, shifted")  # the same sheet with other cell alignments
+
+
+def test_lists_with_cells_on_their_faces_and_far_out(mrs):
+    """positions exactly on cell faces (multiples of the 2.25-m edge), pairs just inside / outside the list radius, unusable
+    positions (NaN, beyond the position limit), coordinates of 1e5 m"""
+    rng = np.random.default_rng(5)
+    edge, R = 2.25, np.sqrt(3.0) + 0.5
+    pts = []
+    for k in range(300):
+        c = np.array([edge * rng.integers(-40, 40), edge * rng.integers(-40, 40), edge * rng.integers(0, 20)], dtype=float)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        pts.append(c)
+        pts.append(c + d * (R - 1e-9 if k % 2 else R + 1e-9) * (1.0 if k % 3 else 0.5))
+    pts = np.array(pts)
+    far = rng.uniform(-1.0, 1.0, (400, 3)) * 12.0 + np.array([1.0e5, -1.0e5, 5.0e4])
+    # coordinates a hair below zero: floor() puts them into cell -1, at its far face (found by the 900-UAV sheet of
+    # tests/cpp/sharded_tick_test.cpp, whose y drifts to -7e-22)
+    hair = rng.uniform(-4, 4, (200, 3))
+    hair[:, 1] = np.where(rng.random(200) < 0.5, -6.9e-22, 5.2e-24)
+    hair[::7, 0] = -1e-300
+    pos = np.concatenate([pts, far, rng.uniform(-20, 20, (300, 3)), hair * [3.0, 1.0, 3.0]])
+    pos[7] = np.nan
+    pos[11, 2] = np.inf
+    check_lists(mrs, pos, "faces, radius edge, far out")
