@@ -868,16 +868,19 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
   // (a search queued ahead of time behind launches that have stalled: lists as usual, no forces or crash flags — see k_query)
   const bool muted = stall_word && *stall_word != 0u;
   __shared__ int4      me_cell[UPW];  // cell, .w = in-cell coordinates
-  __shared__ double    me_pos[UPW][3];
   __shared__ uint32_t  wl_j[WL_CAP + 1];  // work list: member (record index),   (+1: where the items nobody wants are written)
   __shared__ uint16_t  wl_m[WL_CAP + 1];  //            meta
   __shared__ uint32_t  wl_n, next_n, hit_overflow;
   __shared__ uint32_t  nl_j[UPW][LIST_CAP], nl_n[UPW];
-  __shared__ uint32_t  hit_j[UPW][HIT_CAP], hit_n[UPW];
+  constexpr int HITS = 4;  // hits kept per UAV before the reference path takes over (LDS is allocated in 1280-byte steps: with three lanes
+                           // per UAV these 6.3 KB are 6 400, 24 blocks per CU — one round for a 125 k-UAV shard; six hits made it 21)
+  __shared__ uint32_t  hit_j[UPW][HITS], hit_n[UPW];
 
-  const int       lane = threadIdx.x, u = lane / LPU, r = lane % LPU;
+  const int       lane = threadIdx.x, r = lane % LPU;
+  const bool      seated = lane / LPU < UPW;  // (three lanes per UAV leave the 64th lane without one)
+  const int       u      = seated ? lane / LPU : 0;
   const int       i      = blockIdx.x * UPW + u;
-  const bool      active = i < sw.n;
+  const bool      active = seated && i < sw.n;
   const long long gi     = my_offset + i;
   const long long wave_first = my_offset + (long long)blockIdx.x * UPW;
   const uint32_t  ibm    = (1u << ib) - 1u;
@@ -893,13 +896,10 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
   uint32_t   qme;
   const Cell c = cell_q<LISTS>(mx, my, mz, qme);
   MRS_Q2_STAMP(1, qme);
-  if (r == 0) {
-    me_cell[u]   = make_int4(c.x, c.y, c.z, (int)qme);
-    me_pos[u][0] = mx;
-    me_pos[u][1] = my;
-    me_pos[u][2] = mz;
-    nl_n[u]      = 0;
-    hit_n[u]     = 0;
+  if (r == 0 && seated) {
+    me_cell[u] = make_int4(c.x, c.y, c.z, (int)qme);
+    nl_n[u]    = 0;
+    hit_n[u]   = 0;
   }
   if (lane == 0) {
     wl_n         = 0;
@@ -980,12 +980,15 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
         const double* po = reinterpret_cast<const double*>(rec + (ver ? (long long)it.x : wave_first));
         const double2 oxy = *reinterpret_cast<const double2*>(po);
         const double  oz_ = po[2];
+        const double* pm  = reinterpret_cast<const double*>(rec + (wave_first + ow));  // (the owner's position: a cache hit — LDS is what limits the waves per CU)
+        const double2 mxy = *reinterpret_cast<const double2*>(pm);
+        const double  mz_ = pm[2];
         const int     cq = q / 3, ox = cq / 3 - 1, oy = cq % 3 - 1, oz = q % 3 - 1;
         const int4    mc = me_cell[ow];
         if (ver) {
           const Cell oc = cell_of<LISTS>(oxy.x, oxy.y, oz_);
           if (oc.ok && oc.x == mc.x + ox && oc.y == mc.y + oy && oc.z == mc.z + oz) {  // (else: another cell that shares bucket and tag bits)
-            const double d0 = me_pos[ow][0] - oxy.x, d1 = me_pos[ow][1] - oxy.y, d2 = me_pos[ow][2] - oz_;
+            const double d0 = mxy.x - oxy.x, d1 = mxy.y - oxy.y, d2 = mz_ - oz_;
             const double dd = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
             if (dd < (LISTS == 2 ? LIST_R2_2 : LIST_R2)) {
               const uint32_t k = atomicAdd(&nl_n[ow], 1u);
@@ -994,7 +997,7 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
             if (dd < 3.0) {  // close enough for the collision predicate (rare): now the airframe constants of both
               if (qualifies(rec[wave_first + ow], rec[it.x], crash)) {
                 const uint32_t k = atomicAdd(&hit_n[ow], 1u);
-                if (k < (uint32_t)HIT_CAP)
+                if (k < (uint32_t)HITS)
                   hit_j[ow][k] = it.x;
                 else
                   hit_overflow = 1;
@@ -1030,11 +1033,11 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
     const uint32_t nh = hit_n[u];
     if (nh) {
       const PosRecord me = rec[gi];
-      if (hit_overflow && nh > (uint32_t)HIT_CAP) {  // more qualifying partners than the hit list holds: the reference path
+      if (hit_overflow && nh > (uint32_t)HITS) {  // more qualifying partners than the hit list holds: the reference path
         query_lane_sweeps2<LISTS>(me, c, gi, rec, n_total, mask, ib, head, next, crash, rebounce, fx, fy, fz, crashed);
       } else {
         uint32_t prev = 0;
-        for (uint32_t h = 0; h < nh; h++) {  // selection by repeated minimum: nh <= 6, almost always 1
+        for (uint32_t h = 0; h < nh; h++) {  // selection by repeated minimum: nh <= 4, almost always 1
           uint32_t best = 0xFFFFFFFFu;
           for (uint32_t k = 0; k < nh; k++) {
             const uint32_t j = hit_j[u][k];
@@ -1048,7 +1051,7 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
   }
   uint32_t cnt = nl_n[u];
   if (cnt > (uint32_t)LIST_CAP) {  // an incomplete list keeps the next tick in rebuild mode
-    if (r == 0) {
+    if (r == 0 && seated) {
       ctl[cur ^ 1] = 1u;
       atomicAdd(&ctl[6], 1u);  // statistics: UAVs over the list capacity
       if (stall_word) {        // a search queued in stream order: the fused launches behind it must not use the incomplete lists
@@ -1083,8 +1086,10 @@ __global__ void __launch_bounds__(64) k_query2(SwarmDev sw, const PosRecord* rec
 #undef MRS_Q2_STAMP
 }
 
-// lanes per UAV: four (16 UAVs per wave: 6 250 waves at 100 k UAVs, six resident per SIMD) up to 256 k UAVs — measured against two at
-// 100 k / 125 k: 36.9 / 43.1 us per search against 38.1 / 48.1 — and two beyond, where the waves come in rounds anyway (MEASUREMENTS 6.6)
+// lanes per UAV: three — every lane exactly three columns, 21 UAVs per wave, and the 4 762 / 5 953 waves of a 100 k swarm / a 125 k
+// shard resident at once (24 blocks per CU: 106 SGPRs allow six waves per SIMD, 6.3 KB of LDS 24 blocks) — up to half a million UAVs;
+// two beyond, where the waves come in rounds anyway.  Same box, 100 k / 125 k / 200 k / 1 M UAVs: two lanes 38.1 / 48.1 / 62.2 / 317 us
+// per search, three 35.2 / 40.6 / 59.0 / 327, four 37.3 / 44.3 / 60.6 / 316 (MEASUREMENTS 6.6).
 template <int LISTS>
 static void launch_query2(int lpu, SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask, int ib, const uint2* head,
                           const uint2* next, int crash, double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt,
@@ -1096,14 +1101,16 @@ static void launch_query2(int lpu, SwarmDev sw, const PosRecord* rec, long long 
     MRS_Q2_LAUNCH(1);
   else if (lpu == 2)
     MRS_Q2_LAUNCH(2);
+  else if (lpu == 3)
+    MRS_Q2_LAUNCH(3);
   else
     MRS_Q2_LAUNCH(4);
 #undef MRS_Q2_LAUNCH
 }
 static int query_lpu(long long n_own) {
   static const int forced = getenv("MRS_QUERY_LPU") ? atoi(getenv("MRS_QUERY_LPU")) : 0;  // tuning aid
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
-  return n_own > 262144 ? 2 : 4;
+  if (forced >= 1 && forced <= 4) return forced;
+  return n_own > 500000 ? 2 : 3;
 }
 
 }  // namespace
