@@ -497,7 +497,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                 "algorithmic_bytes_per_uav_list_tick": cb,
                 "algorithmic_bytes_per_uav_search_tick": COLLISION_BYTES["search_tick_per_uav"] + COLLISION_BYTES["search_tick_per_candidate"] * kbar,
                 "search_candidates_per_uav": kbar, "search_bytes": search_bytes, "search_ms": search_ms,
-                "search_kernels": "k_pack_insert<1> + k_query<1> (collide.hip), 16 searches back to back between two hipEvents",
+                "search_kernels": "k_pack_insert<1> + k_query2<1, 3> (collide.hip), 16 searches back to back between two hipEvents",
                 "search_achieved": search_bytes / (search_ms * 1e-3) / 1e9, "search_frac": search_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ticks_per_search": (int(ticks) / max(1, int(searches))),
                 "achieved_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9,

@@ -21,7 +21,8 @@
 //            independent of the atomic arrival order.  The head table a later search will fill is wiped by the tick before it.
 //
 // Neighbour lists (single-GPU ticks): UAVs move centimetres per tick, so the partner search above is only REPEATED when it
-// has to be.  A rebuild tick runs insert + query with 2.25-m cells and keeps, per UAV, the ascending list of every UAV
+// has to be.  A rebuild tick runs insert + the list-building query (k_query2: several lanes per UAV, table entries that carry the
+// UAV's position inside its cell — see there) with 2.25-m cells and keeps, per UAV, the ascending list of every UAV
 // within sqrt(3) + SKIN of it, together with the positions at that moment.  The step kernel compares every new position
 // with the recorded one (step_device.inc) and raises a flag once any UAV has moved more than SKIN/2; until then a pair
 // closer than sqrt(3) now was closer than sqrt(3) + SKIN at the rebuild, i.e. is in the lists, and a tick is ONE cheap
