@@ -31,5 +31,9 @@ for lat in 0 10 20 30; do for form in split serial; do timeout -k 10 300 python 
 cat $OUT/sharded_rank_cost.log
 bash tools/gpu_rank_trace.sh 125000 10 > $OUT/rank_trace_10us.txt 2>&1
 f=$(ls -t gpurun_out/ranktrace_125000/prof/*/*_kernel_trace.csv | head -1); python tools/search_timeline.py $f > $OUT/search_timeline.txt 2>&1; tail -3 $OUT/search_timeline.txt
+python tools/search_rate.py 100000 125000 1000000 --volume 64 16 > $OUT/search_rate.txt 2>&1; tail -6 $OUT/search_rate.txt
+V=variants/libmrs_collideflag__DMRS_Q2_CLOCK_1.so  # (bash tools/build_variants.sh collideflag "-DMRS_Q2_CLOCK=1" before the call)
+[ -f $V ] && for n in 100000 125000; do MRS_SWARM_LIB=$V python tools/search_phases.py $n 2>&1 | grep -v amdgpu.ids >> $OUT/search_phases.txt; done
+bash tools/gpu_pmc_search.sh 100000 > $OUT/search_pmc.txt 2>&1
 ./tests/cpp/facade_loop_test | grep -v STATE > $OUT/facade_loop.txt 2>&1; ./tests/cpp/facade_loop_test single | grep -v STATE >> $OUT/facade_loop.txt 2>&1; cat $OUT/facade_loop.txt
 python __graft_entry__.py > $OUT/entry.log 2>&1; python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log

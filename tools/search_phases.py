@@ -18,7 +18,7 @@ g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
 g.debug_search_ms(reps=4)
 count, nbr, cap, radius = g.debug_neighbour_lists()
 first = np.nonzero(count == 6)[0]
-lpu = int(os.environ.get("MRS_QUERY_LPU", "2" if n >= 65536 else "4"))
+lpu = int(os.environ.get("MRS_QUERY_LPU", "3" if n <= 500000 else "2"))  # (collide.hip query_lpu)
 first = first[first % (64 // lpu) == 0]
 ts = nbr[:6, first].astype(np.int64).T  # [waves, 6]
 t0 = ts[:, 0].min()
