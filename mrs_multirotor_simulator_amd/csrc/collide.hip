@@ -264,9 +264,9 @@ __device__ void query_lane_sweeps(const PosRecord& me, const Cell& c, long long 
 #ifndef MRS_TABLE_FACTOR
 #define MRS_TABLE_FACTOR 4
 #endif
-// bucket heads taken into the LDS list per pass.  Sized so that the list-building query keeps its LDS under 20 KB: eight one-wave
-// blocks per CU (what its 195 VGPRs allow), 2048 on the chip — the 1563 blocks of a 100 k swarm then run in ONE round.  With 1024
-// entries (24.6 KB, six blocks per CU = 1536) the last 27 blocks waited for a second round and the search took 56 us instead of 33.
+// bucket heads taken into the LDS list per pass.  Sized so that the kernel keeps its LDS under 20 KB: eight one-wave blocks per CU,
+// 2048 on the chip — the 1563 blocks of a 100 k swarm then run in ONE round (with 1024 entries, 24.6 KB, six blocks per CU = 1536,
+// the last 27 blocks waited for a second round: rounds 2-3, when this kernel also built the neighbour lists — k_query2 does now).
 #ifndef MRS_PAIR_CAP
 #define MRS_PAIR_CAP 640
 #endif
@@ -547,8 +547,6 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
   int4*       me_cell;
   uint32_t*   hit_j;   // [64][HIT_CAP]
   uint32_t*   hit_n;
-  uint32_t*   nl_j;    // [64][LIST_CAP]
-  uint32_t*   nl_n;
   uint32_t*   next_n;
   uint32_t*   hit_overflow;
 };
@@ -558,7 +556,6 @@ struct QueryLds {  // the LDS arrays of k_query, handed to the helper below
 // COMPACTED to the front (slot k < the number of entries read so far, so no unread entry is overwritten) — and the shrunken
 // list is swept again until every chain has ended.  Never more entries than the sweep started with: nothing can overflow, and
 // the later levels of the walk (a few percent of the heads) cost one short pass each instead of a pass over every head.
-template <int LISTS>
 __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int lane, const PosRecord* rec, const uint2* next, long long wave_first,
                                              int crash) {
   // entries per lane and iteration.  Four looked right while the kernel waited on single round trips; since the record loads travel
@@ -611,16 +608,9 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
         const int       ow = (int)(pm[u] & 0xFFu), q = (int)((pm[u] >> 8) & 0xFFu);
         const int4      mc = L.me_cell[ow];
         const PosRecord o  = ob[u];
-        const Cell      oc = cell_of<LISTS>(o.x, o.y, o.z);
+        const Cell      oc = cell_of<0>(o.x, o.y, o.z);
         if (oc.x != mc.x + q / 9 - 1 || oc.y != mc.y + (q / 3) % 3 - 1 || oc.z != mc.z + q % 3 - 1) continue;  // tag collision
         const PosRecord m = L.me_s[ow];
-        if (LISTS) {
-          const double d0 = m.x - o.x, d1 = m.y - o.y, d2 = m.z - o.z;
-          if (((0.0 + d0 * d0) + d1 * d1) + d2 * d2 < (LISTS == 2 ? LIST_R2_2 : LIST_R2)) {
-            const uint32_t k = atomicAdd(&L.nl_n[ow], 1u);
-            if (k < (uint32_t)LIST_CAP) L.nl_j[ow * LIST_CAP + k] = pe[u].x - 1u;
-          }
-        }
         if (!qualifies(m, o, crash)) continue;
         const uint32_t k = atomicAdd(&L.hit_n[ow], 1u);
         if (k < HIT_CAP)
@@ -635,16 +625,10 @@ __device__ __forceinline__ void sweep_window(const QueryLds& L, uint32_t wn, int
   }
 }
 
-template <int LISTS>
+// The search-every-tick query (neighbour lists switched off, or the caller-driven gathered form): one lane per UAV, see above.
 __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec, long long n_total, long long my_offset, uint32_t mask,
                                               const uint2* head, const uint2* next, uint2* head_to_clear, uint32_t table_size, int crash,
-                                              double rebounce, uint32_t* ctl, int cur, int force, uint32_t* nbr, uint32_t* nbr_cnt, int table_id,
-                                              uint32_t* stall_word, volatile uint32_t* hostw, uint32_t stall_tau) {
-  (void)table_id;  // kept in the signature next to the insert kernels' one
-  // A search queued ahead of time (tick_single.hip) behind fused launches that have turned into no-ops — their lists went stale at
-  // an earlier tick — builds its lists as usual (the table protocol stays in step) but must not latch forces or crash flags: the
-  // host repeats the search for the tick that stalled, with that tick's own parameters.
-  const bool muted = LISTS && stall_word && *stall_word != 0u;
+                                              double rebounce) {
   __shared__ PosRecord me_s[64];
   __shared__ int4      me_cell[64];
   __shared__ uint2     pair_e[PAIR_CAP];   // x: candidate index + 1, y: its tag
@@ -652,22 +636,16 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   __shared__ uint32_t  hit_j[64][HIT_CAP];
   __shared__ uint32_t  hit_n[64];
   __shared__ uint32_t  list_total, hit_overflow;
-  __shared__ uint32_t  nl_j[LISTS ? 64 : 1][LISTS ? LIST_CAP : 1];  // neighbour lists under construction
-  __shared__ uint32_t  nl_n[LISTS ? 64 : 1];
 
   const int       lane   = threadIdx.x;
   const int       i      = blockIdx.x * 64 + lane;
   const bool      active = i < sw.n;
-  if (LISTS) {
-    if (!force && ctl[cur] == 0u) return;  // list tick: k_pack_insert has done the work
-    nl_n[lane] = 0;
-  }
   const long long gi     = my_offset + i;
   PosRecord       me;
   me.x = me.y = me.z = __longlong_as_double(0x7ff8000000000000ll);
   me.mass = me.arm_length = me.prop_radius = 0.0;
   if (active) me = rec[gi];
-  const Cell c = cell_of<LISTS>(me.x, me.y, me.z);
+  const Cell c = cell_of<0>(me.x, me.y, me.z);
   me_s[lane]   = me;
   me_cell[lane] = make_int4(c.x, c.y, c.z, 0);
   hit_n[lane]  = 0;
@@ -684,7 +662,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
     uint2          info[27];
     const uint32_t tc = load_heads(c, mask, head, info);
     // this tick's table has been read by this wave's probes: wipe the other one for the next tick (grid-strided, coalesced)
-    if (!LISTS) {
+    {
       const uint32_t stride = gridDim.x * 64u;
       for (uint32_t t = blockIdx.x * 64u + lane; t < table_size; t += stride) head_to_clear[t] = make_uint2(0u, 0u);
     }
@@ -711,11 +689,11 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
 #ifdef MRS_QUERY_CLOCK
   tB = clock_fence(n_heads);
 #endif
-  const QueryLds lds{pair_e, pair_m, me_s, me_cell, &hit_j[0][0], hit_n, &nl_j[0][0], nl_n, &list_total, &hit_overflow};
+  const QueryLds lds{pair_e, pair_m, me_s, me_cell, &hit_j[0][0], hit_n, &list_total, &hit_overflow};
   const long long wave_first = my_offset + (long long)blockIdx.x * 64;
   if (n_heads <= (uint32_t)PAIR_CAP) {
     __syncthreads();
-    sweep_window<LISTS>(lds, n_heads, lane, rec, next, wave_first, crash);
+    sweep_window(lds, n_heads, lane, rec, next, wave_first, crash);
   } else {
     // dense neighbourhood: more heads than the list holds — windows of PAIR_CAP, the heads are probed again per window
     // (cheaper than keeping 27 head words per lane alive across the sweeps of the usual case)
@@ -724,7 +702,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
       load_heads(c, mask, head, info);
       fill_window(info, first_slot, wbase, lane, pair_e, pair_m);
       __syncthreads();
-      sweep_window<LISTS>(lds, n_heads - wbase < (uint32_t)PAIR_CAP ? n_heads - wbase : (uint32_t)PAIR_CAP, lane, rec, next, wave_first, crash);
+      sweep_window(lds, n_heads - wbase < (uint32_t)PAIR_CAP ? n_heads - wbase : (uint32_t)PAIR_CAP, lane, rec, next, wave_first, crash);
     }
   }
   __syncthreads();
@@ -740,7 +718,7 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
   bool   crashed = false;
   if (active && c.ok) {
     if (hit_overflow && hit_n[lane] > HIT_CAP) {  // more qualifying partners than the hit list holds: the reference path
-      query_lane_sweeps<LISTS>(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
+      query_lane_sweeps<0>(me, c, gi, rec, n_total, mask, head, next, crash, rebounce, fx, fy, fz, crashed);
     } else {
       const uint32_t nh = hit_n[lane];
       uint32_t       prev = 0;
@@ -757,42 +735,15 @@ __global__ void __launch_bounds__(64) k_query(SwarmDev sw, const PosRecord* rec,
       }
     }
   }
-  if (LISTS) {
-    // the lists of this wave: ascending, like the order partners are consumed in.  An incomplete list (more than LIST_CAP
-    // neighbours) keeps the next tick in rebuild mode.
-    uint32_t cnt = nl_n[lane];
-    if (cnt > (uint32_t)LIST_CAP) {
-      ctl[cur ^ 1] = 1u;
-      atomicAdd(&ctl[6], 1u);  // statistics: lanes over the list capacity
-      cnt = 0;
-      if (stall_word) {  // a search queued in stream order: the fused launches behind it must not use the incomplete lists
-        *stall_word = stall_tau;
-        __hip_atomic_store(&hostw[CTL_STALL], stall_tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    if (active) {
-      uint32_t prev = 0;
-      for (uint32_t r = 0; r < cnt; r++) {  // selection by repeated minimum, indices are distinct
-        uint32_t best = 0xFFFFFFFFu;
-        for (uint32_t k = 0; k < cnt; k++) {
-          const uint32_t j = nl_j[lane][k];
-          if ((r == 0 || j > prev) && j < best) best = j;
-        }
-        nbr[(size_t)r * sw.n + i] = best;
-        prev = best;
-      }
-      nbr_cnt[i] = cnt;
-    }
-  }
 #ifdef MRS_QUERY_CLOCK  // timing build (tools/query_phases.py): the force columns carry phase durations in 10-ns ticks
 #if MRS_QUERY_CLOCK == 2
-  const unsigned long long tD = clock_fence(LISTS && active ? nbr_cnt[i] : 0u);
+  const unsigned long long tD = clock_fence(0u);
   fx = (double)(tB - t0); fy = (double)(tC - tB); fz = (double)(tD - tC);
 #else
   fx = (double)(tA - t0); fy = (double)(tB - tA); fz = (double)(tC - tB);
 #endif
 #endif
-  if (active && !muted) {
+  if (active) {
     sw.S[(size_t)(F_FEXT + 0) * sw.npad + i] = fx;
     sw.S[(size_t)(F_FEXT + 1) * sw.npad + i] = fy;
     sw.S[(size_t)(F_FEXT + 2) * sw.npad + i] = fz;
@@ -1280,8 +1231,7 @@ extern "C" hipError_t mrs_collide_run(SwarmDev sw, CollideWork** work, const Pos
                        nullptr, 0u, nullptr, nullptr, 0, 0.0, nullptr, nullptr, 0);
   else
     hipLaunchKernelGGL(k_insert<false>, dim3(gN), dim3(256), 0, st, rec, n_total, mask, head, w->next);
-  hipLaunchKernelGGL(k_query<false>, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash,
-                     rebounce, nullptr, 0, 1, nullptr, nullptr, 0, nullptr, nullptr, 0u);
+  hipLaunchKernelGGL(k_query, dim3((sw.n + 63) / 64), dim3(64), 0, st, sw, rec, n_total, my_offset, mask, head, w->next, other, T, crash, rebounce);
   return hipGetLastError();
 }
 

@@ -15,7 +15,9 @@ lib = "/tmp/qph/libmrs_swarm_clock.so"
 subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, o] + [os.path.join(OBJ, f) for f in
                       ("step_kernel_literal.o", "step_kernel_fast.o", "outputs.o", "host_api.o", "tick_single.o", "tick_sharded.o", "transport_rccl.o", "transport_local.o", "transport_peer.o")])
 os.environ["MRS_SWARM_LIB"] = lib
-LISTS = os.environ.get("QPH_LISTS", "0") == "1"  # time the list-building search (a host write before each call forces it)
+if os.environ.get("QPH_LISTS", "0") == "1":
+    sys.exit("the list-building query has its own stamps: tools/search_phases.py (this tool times the plain search-every-tick query)")
+LISTS = False
 os.environ["MRS_NEIGHBOUR_LISTS"] = "1" if LISTS else "0"
 import mrs_multirotor_simulator_amd as M
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
