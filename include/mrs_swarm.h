@@ -384,8 +384,8 @@ int mrs_swarm_debug_component(mrs_swarm_t* s, int32_t component, int32_t first, 
 int mrs_swarm_debug_search_ms(mrs_swarm_t* s, int32_t reps, int32_t crash, double rebounce, double* avg_ms);
 
 /* test hook: ONE forced neighbour search on the current positions (it latches the forces / crash flags of
- * handleCollisions(true, crash, rebounce)), then the lists it built: count[i] = listed neighbours of UAV i (0 for every UAV when some
- * list came out incomplete), nbr[r * n + i] = the r-th of them in ascending index, r < min(count[i], *list_cap); rows >= count[i]
+ * handleCollisions(true, crash, rebounce)), then the lists it built: count[i] = listed neighbours of UAV i (0 for a UAV with
+ * more neighbours than a list holds), nbr[r * n + i] = the r-th of them in ascending index, r < min(count[i], *list_cap); rows >= count[i]
  * hold stale values.  `nbr` holds list_cap_in rows of n entries; *list_cap returns the library's list capacity.  What the lists must
  * hold (a superset of nanoflann's radiusSearch(3.0) result, src/multirotor_simulator.cpp:326): every UAV closer than sqrt(3) + skin. */
 int mrs_swarm_debug_neighbour_lists(mrs_swarm_t* s, int32_t crash, double rebounce, uint32_t* count, uint32_t* nbr, int32_t list_cap_in, int32_t* list_cap,

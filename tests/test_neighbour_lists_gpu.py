@@ -94,3 +94,36 @@ def test_lists_with_cells_on_their_faces_and_far_out(mrs):
     pos[7] = np.nan
     pos[11, 2] = np.inf
     check_lists(mrs, pos, "faces, radius edge, far out")
+
+
+@pytest.mark.parametrize("name", ["dense", "sparse", "grid12", "tmux400"])
+def test_lists_hold_what_the_reference_kdtree_returned(mrs, name):
+    """tests/golden/nanoflann_radius_sets.npz: outputs of the REFERENCE's own nanoflann radiusSearch(3.0) (made by
+    tests/golden/make_golden.py from oracle/_ref).  Every neighbour it returned for UAV i (itself excluded, src/multirotor_simulator.cpp:335)
+    must be on the GPU's list of i; what the list holds beyond that lies between sqrt(3) and the list radius."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nanoflann_radius_sets.npz"))
+    pts, off, idx, d2 = (g[f"{name}_{k}"] for k in ("points", "offsets", "indices", "d2"))
+    n = len(pts)
+    s = mrs.Swarm(n)
+    s.construct(0, n, mrs.model_params("x500"), pts, np.zeros(n))
+    count, nbr, cap, radius = s.debug_neighbour_lists()
+    within = brute_lists(pts, radius * radius * (1.0 + 1e-9) + 1e-5)
+    extra = over = 0
+    for i in range(n):
+        ref = sorted(int(j) for j in idx[off[i]:off[i + 1]] if j != i)
+        if len(within[i]) > cap:  # a list that does not fit is reported empty (and keeps the library searching every tick: test_golden covers that form)
+            assert count[i] == 0
+            over += 1
+            continue
+        got = nbr[:count[i], i].astype(np.int64).tolist()
+        assert got == sorted(got), f"{name}: list of {i} not ascending"
+        missing = [j for j in ref if j not in got]
+        assert not missing, f"{name}: UAV {i}: the kd-tree returned {missing}, the list holds {got}"
+        for j in got:
+            if j not in ref:
+                d = pts[i] - pts[j]
+                dd = ((0.0 + d[0] * d[0]) + d[1] * d[1]) + d[2] * d[2]
+                assert 3.0 <= dd < radius * radius * (1 + 1e-9) + 1e-5, f"{name}: UAV {i} lists {j} at squared distance {dd}"
+                extra += 1
+    print(f"{name}: {n} UAVs, every kd-tree neighbour listed; {extra} more entries between sqrt(3) and {radius:.3f} m; {over} UAVs with more than {cap} neighbours")
