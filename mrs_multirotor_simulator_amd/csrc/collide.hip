@@ -1060,7 +1060,8 @@ static void launch_query2(int lpu, SwarmDev sw, const PosRecord* rec, long long 
 #undef MRS_Q2_LAUNCH
 }
 static int query_lpu(long long n_own) {
-  static const int forced = getenv("MRS_QUERY_LPU") ? atoi(getenv("MRS_QUERY_LPU")) : 0;  // tuning aid
+  const char* e = getenv("MRS_QUERY_LPU");  // tuning aid, and how the tests reach every instantiation (read per search: a search is rare)
+  const int   forced = e ? atoi(e) : 0;
   if (forced >= 1 && forced <= 4) return forced;
   return n_own > 500000 ? 2 : 3;
 }

@@ -60,6 +60,16 @@ def test_lists_of_a_random_swarm(mrs):
     check_lists(mrs, pos, "random, 30 m^3 per UAV")
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_lists_with_other_lanes_per_uav(mrs, monkeypatch, lanes):
+    """the query's other instantiations (three lanes per UAV is the default up to 500 000 UAVs, two beyond; MRS_QUERY_LPU forces one)"""
+    monkeypatch.setenv("MRS_QUERY_LPU", str(lanes))
+    rng = np.random.default_rng(20 + lanes)
+    n = 6000
+    side = (n * 12.0) ** (1 / 3)  # 12 m^3 per UAV: chains and lists of a dozen entries
+    check_lists(mrs, rng.uniform(-side / 2, side / 2, (n, 3)), f"{lanes} lane(s) per UAV, 12 m^3 per UAV")
+
+
 def test_lists_of_a_dense_sheet(mrs):
     """pairs 0.55 m apart, 1.9 m between pairs, rows 2.5 m apart: most cells hold two or three UAVs — every bucket is a chain"""
     m = 900
