@@ -137,3 +137,26 @@ def test_lists_hold_what_the_reference_kdtree_returned(mrs, name):
                 assert 3.0 <= dd < radius * radius * (1 + 1e-9) + 1e-5, f"{name}: UAV {i} lists {j} at squared distance {dd}"
                 extra += 1
     print(f"{name}: {n} UAVs, every kd-tree neighbour listed; {extra} more entries between sqrt(3) and {radius:.3f} m; {over} UAVs with more than {cap} neighbours")
+
+
+@pytest.mark.parametrize("crash", [False, True])
+def test_search_tick_with_more_contacts_than_the_hit_list_holds(mrs, oracle, crash):
+    """clusters of eight UAVs inside half a metre: seven partners in contact each — more than the four hits the query keeps per UAV,
+    so the forces of the search tick come from its reference path; ascending-index sums against the oracle (src/multirotor_simulator.cpp:329-358)"""
+    rng = np.random.default_rng(77)
+    centres = rng.uniform(-30, 30, (40, 3)) + [0, 0, 50]
+    pos = np.concatenate([c + rng.uniform(-0.25, 0.25, (8, 3)) for c in centres] + [rng.uniform(-40, 40, (500, 3)) + [0, 0, 50]])
+    n = len(pos)
+    po = helpers.oracle_params("x500")
+    o = oracle.OracleSwarm(n)
+    o.construct(0, n, po, pos, np.zeros(n))
+    o.handle_collisions(True, crash, 100.0)
+    g = mrs.Swarm(n, arith=mrs.ARITH_LITERAL)
+    g.construct(0, n, helpers.to_product_params(mrs, po), pos, np.zeros(n))
+    g.handle_collisions(True, crash, 100.0)
+    if crash:
+        assert np.array_equal(g.has_crashed(), o.has_crashed()) and g.has_crashed()[:320].all()
+    else:
+        fo = o.get_external_force()
+        assert (np.abs(fo[:320]).sum(axis=1) > 0).all()
+        helpers.assert_close(g.get_external_force(), fo, 1e-12, "forces of eight-UAV clusters")
