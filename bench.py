@@ -129,6 +129,9 @@ def parse():
     ap.add_argument("--uavs", type=int, default=100_000, help="UAVs per GPU")
     ap.add_argument("--volume-per-uav", type=float, default=64.0, help="collision workloads: m^3 of air space per UAV")
     ap.add_argument("--workload", choices=["actuator", "position", "position+collisions"], default="actuator")
+    ap.add_argument("--order", choices=["random", "xcell", "morton"], default="random",
+                    help="collision workloads: UAV indices unrelated to positions (the generator's order), or sorted at spawn by x-major "
+                         "list cells / by a Morton key of the list cells (the caller's indices then follow space)")
     ap.add_argument("--arith", choices=["literal", "fast"], default="fast",
                     help="fast: FMA + rsqrt arithmetic (within 1e-6 of the reference, the production flavour); literal: reference op order")
     ap.add_argument("--substeps", type=int, default=1, help="makeStep rounds fused per launch (state kept in registers)")
@@ -174,7 +177,19 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def make_inputs(n, workload, seed, volume_per_uav=64.0, n_motors=4):
+def spatial_order(x, order, cell=2.25):
+    """permutation that sorts UAVs by the cell of their position: x-major (cx, cy, cz) or a Morton key of the three cell indices"""
+    c = np.floor((x - x.min(axis=0)) / cell).astype(np.int64)
+    if order == "xcell":
+        return np.lexsort((c[:, 2], c[:, 1], c[:, 0]))
+    key = np.zeros(len(x), dtype=np.int64)
+    for b in range(20):
+        for a in range(3):
+            key |= ((c[:, a] >> b) & 1) << (3 * b + a)
+    return np.argsort(key, kind="stable")
+
+
+def make_inputs(n, workload, seed, volume_per_uav=64.0, n_motors=4, order="random"):
     from mrs_multirotor_simulator_amd import synthetic  # numpy only: the GPU legs of the bench never touch oracle/ or tests/
     rng = np.random.default_rng(seed)
     if workload == "config2":
@@ -195,6 +210,10 @@ def make_inputs(n, workload, seed, volume_per_uav=64.0, n_motors=4):
         st = synthetic.random_state(rng, n, n_motors, tilted=True)
         st["x"] = rng.uniform(0, 1, (n, 3)) * [side * 2, side * 2, side / 4] + [0, 0, 5]
         cmd = np.concatenate([st["x"] + rng.uniform(-5, 5, (n, 3)), rng.uniform(-3.14, 3.14, (n, 1))], axis=1)
+        if order != "random":
+            perm = spatial_order(st["x"], order)
+            st = {k: v[perm] for k, v in st.items()}
+            cmd = cmd[perm]
     return st, cmd
 
 
@@ -367,7 +386,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
     arith = args.arith if arith is None else arith
     substeps = args.substeps if substeps is None else substeps
     n_motors = airframes.AIRFRAMES[airframe]["n_motors"]
-    st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav, n_motors=n_motors)
+    st, cmd = make_inputs(n, workload, seed=seed + R.rank, volume_per_uav=args.volume_per_uav, n_motors=n_motors, order=args.order)
     sw = M.Swarm(n, device=R.local, arith=M.ARITH_FAST if arith == "fast" else M.ARITH_LITERAL)
     if workload == "config2":
         sw.construct(0, n, M.model_params(airframe, ground_enabled=True), st["x"], st["heading"])
@@ -453,7 +472,7 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                       f"over ranks, median) and {len(ev)} regions with a hipEvent pair around the region's launches (device_ms_per_step / "
                       "value_device_time: what the roofline is computed from)",
             "config": {"workload": wl, "uavs_per_gpu": n, "airframe": airframe, "n_motors": n_motors, "arith": arith,
-                       "substeps_per_launch": substeps, "parallelism": f"{world} independent shard(s), no collective on the data path"},
+                       "substeps_per_launch": substeps, "order": args.order if coll else "n/a", "parallelism": f"{world} independent shard(s), no collective on the data path"},
             # `peak` is the HBM3E spec figure in every regime (comparable across sizes); while the touched state fits the 256 MiB Infinity
             # Cache the operative limit is that cache, not HBM: `bound` says so, and the guide's measured lower bound for it is given
             "roofline": {"bound": "infinity-cache" if resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

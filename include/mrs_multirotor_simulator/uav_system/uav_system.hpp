@@ -58,8 +58,10 @@ public:
   struct Stats { long long rounds = 0, consumed = 0, single_steps = 0, rollbacks = 0, state_hits = 0, state_misses = 0, grows = 0; };
 
   static UavPool& instance() {
-    static UavPool pool;
-    return pool;
+    // never destroyed: UavSystem objects of static storage may outlive any function-local static constructed after them, and their
+    // destructors call release(); the swarms go with the process (no HIP call during runtime teardown)
+    static UavPool* const pool = new UavPool;
+    return *pool;
   }
   // before the first UavSystem is created: device and arithmetic flavour of the pool (default: current device, FAST; the environment
   // variable MRS_FACADE_ARITH=literal selects the reference's operation order, MRS_FACADE_SPECULATE=0 steps every object on its own)
@@ -211,6 +213,7 @@ public:
         ahead_[(size_t)k]  = used_[(size_t)k] && k != slot;
         cached_[(size_t)k] = used_[(size_t)k];
         n_ahead_ += ahead_[(size_t)k];
+        if (!used_[(size_t)k]) dirty_[(size_t)k] = 1;  // the launch has stepped the free slots too: no longer UavSystem()'s zero state
       }
       round_of_[(size_t)slot] = round_;
       stats_.rounds++;

@@ -1442,7 +1442,7 @@ __global__ void k_search_reset(uint32_t* fctl, uint32_t* map, long long n_map, u
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_map) map[i] = MRS_NO_SLOT;
   if (i < n_blocks) blk_class[i] = 0u;
-  if (i < CTL_WORDS && i != CTL_ERROR) fctl[i] = 0u;
+  if (i < CTL_WORDS && i != CTL_ERROR && i != CTL_BADSLOT) fctl[i] = 0u;  // (sticky: the host reads both once per call, a call may hold several searches)
   for (long long v = i; v < n_xvec; v += (long long)gridDim.x * blockDim.x) xalloc[v] = make_uint4(0u, 0u, 0u, 0u);
 }
 

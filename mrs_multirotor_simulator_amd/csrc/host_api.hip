@@ -483,6 +483,7 @@ int mrs_swarm_create(int32_t n_uavs, int32_t device_id, mrs_swarm_t** out) {
   HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_join_b, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming));
   s->cstream = s->stream;
   if (const char* e = getenv("MRS_SPLIT_CU_RESERVE")) s->cu_reserve = atoi(e);
   if (s->cu_reserve > 0) {
@@ -561,6 +562,7 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
   if (s->stream_i) (void)hipStreamDestroy(s->stream_i);
   if (s->ev_join_b) (void)hipEventDestroy(s->ev_join_b);
+  if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return MRS_OK;
@@ -951,11 +953,20 @@ int mrs_swarm_copy_uavs(mrs_swarm_t* dst, int32_t dst_first, mrs_swarm_t* src, i
     if (memcmp(&dst->keys[t], &src->keys[t], sizeof(TypeKey)) != 0)
       return fail(MRS_ERR_TYPES, "copy_uavs: the two swarms are not clones of each other (their type tables differ)");
   }
-  HIPCHK(hipStreamSynchronize(src->stream));  // the source columns are complete
+  // No host synchronisation: every write to a swarm's columns is work on its `stream` (settle() above has joined the others), so
+  // the copy goes behind the source's work on the SOURCE's stream, after the destination's earlier work (event), and the
+  // destination's later work waits for it (event); whatever overwrites the source afterwards is behind the copy in stream order.
+  if (dst != src) {
+    HIPCHK(hipEventRecord(dst->ev_copy, dst->stream));
+    HIPCHK(hipStreamWaitEvent(src->stream, dst->ev_copy, 0));
+  }
   HIPCHK(hipMemcpy2DAsync(dst->dS + dst_first, sizeof(double) * (size_t)dst->npad, src->dS + src_first, sizeof(double) * (size_t)src->npad,
-                          sizeof(double) * (size_t)count, F_COUNT, hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(hipMemcpyAsync(dst->dF + dst_first, src->dF + src_first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, dst->stream));
-  HIPCHK(hipStreamSynchronize(dst->stream));  // (the caller may overwrite the source right away)
+                          sizeof(double) * (size_t)count, F_COUNT, hipMemcpyDeviceToDevice, src->stream));
+  HIPCHK(hipMemcpyAsync(dst->dF + dst_first, src->dF + src_first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToDevice, src->stream));
+  if (dst != src) {
+    HIPCHK(hipEventRecord(src->ev_copy, src->stream));
+    HIPCHK(hipStreamWaitEvent(dst->stream, src->ev_copy, 0));
+  }
   for (int k = 0; k < count; k++) {
     const uint16_t t = src->uav_type[(size_t)src_first + k];
     if (dst->uav_type[(size_t)dst_first + k] != t) {

@@ -149,6 +149,7 @@ struct mrs_swarm {
   // streaming interior waves.  `cstream`: where collectives and boundary launches go right now (`stream` outside split segments).
   hipStream_t stream_b = nullptr, stream_i = nullptr, cstream = nullptr;
   hipEvent_t  ev_join_b = nullptr;
+  hipEvent_t  ev_copy = nullptr;   // mrs_swarm_copy_uavs between two swarms: orders the copy against the other swarm's stream
   int         cu_reserve = 0;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t  ev_end2 = nullptr;   // profiling: end of the second stream's part of a split run (recorded before the join)

@@ -106,5 +106,25 @@ int main(int argc, char** argv) {
   std::printf("TIMED rounds %lld single_steps %lld ticks %d\n", s1.rounds - s_warm.rounds, s1.single_steps - s_warm.single_steps, timed);
   std::printf("CHECKSUM %.17g\n", checksum);
   for (int i : {0, 5, 6, 7, 8, 17, 40, 300, 399}) print_state("STATE", i, uavs_[(size_t)i]->getState());
+  if (!single) {
+    // UavSystem() created AFTER rounds have run: the rounds' launches step every slot of the pool, the free ones too —
+    // a late default-constructed object must still start from the reference's zero state (uav_system.hpp:127-133), whether its slot
+    // was used before (the first: slot of the object destroyed at tick 200) or never (the second)
+    UavSystem late_a, late_b;
+    std::printf("LATESLOTS %d %d\n", late_a.poolSlot(), late_b.poolSlot());
+    print_state("LATE0", 0, late_a.getState());
+    print_state("LATE0", 1, late_b.getState());
+    reference::Actuators a;
+    a.motors = Eigen::VectorXd::Zero(4);
+    for (int m = 0; m < 4; m++) a.motors(m) = 0.55 + 0.01 * m;
+    late_a.setInput(a);
+    late_b.setInput(a);
+    for (int k = 0; k < 3; k++) {
+      late_a.makeStep(dt);
+      late_b.makeStep(dt);
+    }
+    print_state("LATE3", 0, late_a.getState());
+    print_state("LATE3", 1, late_b.getState());
+  }
   return 0;
 }

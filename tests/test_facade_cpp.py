@@ -37,7 +37,7 @@ def test_unchanged_per_uav_loop_over_pooled_objects(mrs, oracle):
     exe = build_exe(mrs, "facade_loop_test")
     out = subprocess.run([exe], capture_output=True, text=True, check=True, timeout=600).stdout
     rows = [ln.split() for ln in out.splitlines()]
-    stats = {r[0]: r[1:] for r in rows if r[0] != "STATE"}
+    stats = {r[0]: r[1:] for r in rows if r[0] not in ("STATE", "LATE0", "LATE3")}
     st = {k: int(v) for k, v in zip(stats["STATS"][0::2], stats["STATS"][1::2])}
     timed = {k: int(v) for k, v in zip(stats["TIMED"][0::2], stats["TIMED"][1::2])}
     n, ticks, dt = 400, 300, 0.001
@@ -86,6 +86,26 @@ def test_unchanged_per_uav_loop_over_pooled_objects(mrs, oracle):
         helpers.assert_close(got["motor_rpm"], so["motor_rpm"][i, :4], helpers.RTOL_NORTH_STAR, f"UAV {i}: rpm")
         seen += 1
     assert seen == 9
+    # UavSystem() constructed after 300 rounds (one in a reused slot, one in a slot no object ever held): the reference's zero state,
+    # and the same first steps as a fresh oracle object
+    late = O.OracleSwarm(1)
+    s0 = late.get_state(0, 1)
+    late.set_input(0, 1, O.ACTUATOR_CMD, [[0.55, 0.56, 0.57, 0.58]])
+    late.step_n(dt, 3)
+    s3 = late.get_state(0, 1)
+    slots = [int(v) for v in stats["LATESLOTS"]]
+    assert slots[0] < n <= slots[1], slots  # (reused, never used)
+    n_late = 0
+    for r in rows:
+        if r[0] not in ("LATE0", "LATE3"):
+            continue
+        ref, v = (s0 if r[0] == "LATE0" else s3), np.array(r[2:], dtype=float)
+        got = dict(x=v[0:3], v=v[3:6], R=v[6:15].reshape(3, 3), omega=v[15:18], motor_rpm=v[18:22])
+        for k in ("x", "v", "R", "omega"):
+            helpers.assert_close(got[k], ref[k][0], helpers.RTOL_FAST, f"late object {r[1]} {r[0]}: {k}")
+        helpers.assert_close(got["motor_rpm"], ref["motor_rpm"][0, :4], helpers.RTOL_FAST, f"late object {r[1]} {r[0]}: rpm")
+        n_late += 1
+    assert n_late == 4
     # launches: every timed tick is ONE round (step launch + state pack = two kernels) but for the disturbances
     assert timed["rounds"] >= timed["ticks"] - 3 and timed["single_steps"] <= 8, (timed, st)
     # (the first tick after construction is the pool's observation round: every object steps on its own and reads the device once)
