@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 DT = 0.001
+# MRS_BENCH_REHEARSAL=1: the --gpus N path with every rank on cuda:0 and a gloo process group (NOTES["rehearsal"]) — a one-GPU box can
+# run the code an 8-GPU node will run, so that the node is not its first execution
+REHEARSAL = os.environ.get("MRS_BENCH_REHEARSAL") == "1"
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6300.0  # what a plain read+write stream reaches according to the same guide (measured here: 6.0-6.2 TB/s)
 INFINITY_CACHE_BYTES = 256 * 2 ** 20
@@ -59,6 +62,53 @@ BYTES_MOVED_PER_UAV_STEP = {k: bytes_moved_per_uav_step(k) for k in ("actuator",
 # collision pass: a list tick reads the list head + count and writes the force for every UAV, and gathers the
 # positions of the listed partners of the p UAVs that have any; a search tick is the SURVEY figure
 COLLISION_BYTES = {"list_tick_per_uav": 28, "list_tick_per_uav_with_partner": 150, "search_tick_per_uav": 92, "search_tick_per_candidate": 24}
+
+
+# What the fields of the line mean and how they are measured.  NOT printed in the line (the driver keeps the last 8 KB of stdout: the
+# line must hold every number, so the prose lives here, in DESIGN.md §6 and behind `python bench.py --explain`).
+NOTES = {
+    "timing": "regions of exactly K steps, each bracketed by barrier + synchronize on both sides, in two passes: by time.perf_counter() "
+              "(ms_per_step / value: wall clock, host start-up and synchronize latency of the region included, MAX over ranks, median over "
+              "`regions` regions) and with a hipEvent pair around the region's launches (device_ms_per_step / value_device_time: what the "
+              "roofline is computed from)",
+    "roofline": "hipEvents around each timed region: one before the first launch, one per stream after its last launch (the later of the two "
+                "ends the region; joining the streams afterwards is bookkeeping): elapsed / steps, inter-launch gaps included, median over the "
+                "regions; with two concurrent half-swarm launches per step `achieved` is the bytes of both over that time.  `achieved` prices "
+                "the ALGORITHMIC bytes (SURVEY 8d); `moved_GBps` the bytes the kernel really moves (elided v_prev / F_ext / init_z columns), "
+                "and `frac_of_achievable` holds those against the 6.3 TB/s a read+write stream reaches.  `traffic` = rocprofv3 --pmc "
+                "FETCH_SIZE x 2 + WRITE_SIZE per step (separate passes, child runs before this process touches the GPU).  In the "
+                "`infinity-cache-resident` regime the state (touched_bytes) fits the 256 MiB Infinity Cache, so HBM bandwidth is not the "
+                "operative limit there (`bound`); the `hbm_streaming` sub-record is the same kernel on 4 M UAVs, where every byte comes from HBM",
+    "roofline_collision": "whole tick = fused step + collision launch, plus the neighbour search amortised over the ticks between two searches, "
+                          "over (step bytes + list-tick bytes); search_* = one search on its own (k_pack_insert<1> + k_query2<1, 3>, 16 searches "
+                          "back to back between two hipEvents) against SURVEY 8d's (92 + 24 k) B per UAV, k measured on the run's positions; "
+                          "per-kernel times: profiles/r05_collision_tick_*",
+    "sub_records": "hbm_streaming: the headline kernel on 4 M UAVs; config4: BASELINE configs[3] (100 000 UAVs, position references + "
+                   "collisions + ground) as mrs_swarm_tick_n runs it; literal: the bit-faithful flavour on the headline workload; config2: "
+                   "BASELINE configs[1] (400 f550 on the tmux grid); io_tick: config 3 with the publisher payload of every UAV downloaded and a "
+                   "command block uploaded every tick (SURVEY 8f rank 2), serial and pipelined; sharded_rank_standin: one rank of 8 x 125 000 "
+                   "alone on the GPU behind a fixed-latency stand-in collective (NOT a multi-GPU measurement); config5: BASELINE configs[4] "
+                   "through mrs_swarm_tick_sharded_n on the ranks of this run",
+    "rehearsal": "MRS_BENCH_REHEARSAL=1: the --gpus N code path (torch.distributed.run child, one process per rank, process group, MAX over "
+                 "ranks, config-5 leg, guarded peer-window child run) with every rank on cuda:0 and a gloo process group; the config-5 exchange "
+                 "is a host all-gather over gloo or the peer windows over IPC.  Exercises the code, measures nothing: n_devices says 1",
+}
+
+
+def _round_floats(o, digits=7):
+    """nested records carry floats at 7 significant digits (the top-level value / ms_per_step stay exact)"""
+    if isinstance(o, float):
+        return float(f"{o:.{digits}g}") if np.isfinite(o) else o
+    if isinstance(o, dict):
+        return {k: _round_floats(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, digits) for v in o]
+    return o
+
+
+def compact_line(out):
+    """the ONE line: top-level scalars as they are, every nested record with rounded floats"""
+    return {k: (_round_floats(v) if isinstance(v, (dict, list)) else v) for k, v in out.items()}
 
 
 def pmc_traffic(args, n, workload=None):
@@ -145,6 +195,7 @@ def parse():
                     help="hbm_streaming (4 M UAVs) and config4 (100 k UAVs with collisions) sub-records; auto = in the default N=1 run")
     ap.add_argument("--traffic", choices=["live", "profile", "off"], default="live",
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs of the same workload (N=1 only), profile = the committed summary")
+    ap.add_argument("--explain", action="store_true", help="print what the fields of the line mean and how they are measured, then exit")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run rocprofv3 wraps for --traffic live
     ap.add_argument("--config5-timeout", type=float, default=240.0, help="seconds after which the config-5 leg is given up (the headline line is printed regardless)")
     ap.add_argument("--config5-uavs", type=int, default=1_000_000, help="UAVs of the config-5 leg, all ranks together")
@@ -166,7 +217,7 @@ def spawn_ranks(args):
     the GPU: device_count() does not initialise it on this image) and leave with its exit code."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < (1 if REHEARSAL else args.gpus):
         raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {have} GPU(s)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -256,8 +307,7 @@ def cpu_baseline(args, st, cmd, workload=None, uavs=None, airframe="x500", secon
         if el > seconds:
             break
     out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port", "compiler_flags": "gcc " + flags,
-           "sample": f"{n} {airframe} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c ({flags}), 1 thread "
-                     "(the reference's loop is serial, src/multirotor_simulator.cpp:211-213)"}
+           "sample": f"{n} {airframe} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c, 1 thread (the reference's loop is serial)"}
     if coll and O.ref_lib() is not None:
         # the reference's OWN broadphase on the same positions: nanoflann build + one radius search per UAV
         # (oracle/_ref, compiled from the reference tree) — "kind": "reference" for this part of the tick
@@ -269,9 +319,7 @@ def cpu_baseline(args, st, cmd, workload=None, uavs=None, airframe="x500", secon
             reps += 1
         ms = (time.perf_counter() - t0) / reps * 1e3
         out["collision_broadphase_reference"] = {"kind": "reference", "ms_per_tick": ms, "uavs": n, "us_per_uav_tick": ms * 1e3 / n,
-                                                 "sample": f"the reference's nanoflann kd-tree (oracle/_ref, compiled from the reference tree): "
-                                                           f"build + {n} radius searches, 1 thread — what handleCollisions does every tick "
-                                                           "(src/multirotor_simulator.cpp:303-326)"}
+                                                 "sample": f"the reference's own nanoflann (oracle/_ref): build + {n} radius searches, 1 thread"}
     if not coll and workload != "config2":  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
         cores = os.cpu_count() or 1
         k, t0 = 0, time.perf_counter()
@@ -294,12 +342,18 @@ class Ranks:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+        self.rehearsal = REHEARSAL and self.world > 1
+        if self.rehearsal:
+            self.local = 0  # every rank on the one device
         if self.local >= torch.cuda.device_count():
             raise SystemExit(f"rank {self.rank}: local rank {self.local} has no GPU ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(self.local)
         self.use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched through torch.distributed.run
         if self.use_dist:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+            if self.rehearsal:  # (RCCL refuses two ranks on one device)
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
 
     def barrier(self, sync_local):
         sync_local()
@@ -310,7 +364,7 @@ class Ranks:
     def max_over_ranks(self, x):
         if not self.use_dist:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.rehearsal else "cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -467,10 +521,6 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "regions": len(times), "device_ms_per_step": el / steps * 1e3, "value_device_time": world * n * steps / el,
             "first_region_wall_ms_per_step": times[0] / steps * 1e3,
-            "timing": f"regions of exactly {steps} steps, each bracketed by barrier + synchronize on both sides, in two passes: {len(times)} regions by "
-                      "time.perf_counter() (ms_per_step / value: wall clock, host start-up and synchronize latency of the region included, MAX "
-                      f"over ranks, median) and {len(ev)} regions with a hipEvent pair around the region's launches (device_ms_per_step / "
-                      "value_device_time: what the roofline is computed from)",
             "config": {"workload": wl, "uavs_per_gpu": n, "airframe": airframe, "n_motors": n_motors, "arith": arith,
                        "substeps_per_launch": substeps, "order": args.order if coll else "n/a", "parallelism": f"{world} independent shard(s), no collective on the data path"},
             # `peak` is the HBM3E spec figure in every regime (comparable across sizes); while the touched state fits the 256 MiB Infinity
@@ -485,18 +535,10 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                          "frac_moved_of_peak": moved / HBM_PEAK_GBS,
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": moved / HBM_ACHIEVABLE_GBS,
                          "kernel": kernel_name if not coll
-                         else "whole tick: " + kernel_name + " + neighbour search every ~27 ticks (time per tick, bytes of the step only)",
+                         else kernel_name + " + search every ~27 ticks (time per tick, bytes of the step)",
                          "kernel_avg_ms": kern_ms, "launches": n_launch,
                          "algorithmic_bytes_per_uav_step": b_alg,
-                         "concurrent_launches_per_step": launches_per_step,
-                         "method": "hipEvents around each timed region: one before the first launch, one per stream after its last launch (the later "
-                                   "of the two ends the region; joining the streams afterwards is bookkeeping): elapsed / steps, inter-launch gaps "
-                                   "included, median over the regions; with two concurrent half-swarm launches "
-                                   "per step `achieved` is the bytes of both over that time.  `achieved` prices the ALGORITHMIC bytes (SURVEY 8d); "
-                                   "`moved_GBps` the bytes the kernel really moves (elided v_prev / F_ext / init_z columns), and `frac_of_achievable` "
-                                   "holds those against the 6.3 TB/s a read+write stream reaches.  In the `infinity-cache-resident` regime the state "
-                                   "(touched_bytes) fits the 256 MiB Infinity Cache, so HBM bandwidth is not the operative limit there (`bound`); "
-                                   "the `hbm_streaming` sub-record of this line is the same kernel on 4 M UAVs, where every byte comes from HBM"},
+                         "concurrent_launches_per_step": launches_per_step},
         }
         if coll:
             ticks, searches = sw.collision_stats()
@@ -520,20 +562,29 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                 "search_achieved": search_bytes / (search_ms * 1e-3) / 1e9, "search_frac": search_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ticks_per_search": (int(ticks) / max(1, int(searches))),
                 "achieved_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9,
-                "frac_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "whole tick = fused step + collision launch, plus the neighbour search amortised over the ticks between two searches, over "
-                        "(step bytes + list-tick bytes); search_* = one search on its own against SURVEY 8d's (92 + 24 k) B per UAV; per-kernel "
-                        "times: profiles/r04_collision_tick_*"}
+                "frac_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     del sw
     return out, st, cmd
 
 
 SUB_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "regions", "device_ms_per_step", "value_device_time", "config", "roofline", "roofline_collision", "cpu_baseline")
+SUB_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "moved_GBps", "frac_of_achievable", "kernel", "kernel_avg_ms", "launches",
+                     "concurrent_launches_per_step", "algorithmic_bytes_per_uav_step")
+SUB_CONFIG_DROP = ("parallelism", "n_motors", "substeps_per_launch", "ticks_evaluated_by_the_next_step_launch")
 
 
 def sub_record(rec):
-    """the fields of a full record that a sub-record of the headline line keeps"""
-    return {k: rec[k] for k in SUB_KEYS if k in rec}
+    """the fields of a full record that a sub-record of the headline line keeps (numbers; the prose is NOTES)"""
+    out = {k: rec[k] for k in SUB_KEYS if k in rec}
+    if "roofline" in out:
+        out["roofline"] = {k: out["roofline"][k] for k in SUB_ROOFLINE_KEYS if k in out["roofline"]}
+    if "config" in out:
+        out["config"] = {k: v for k, v in out["config"].items() if k not in SUB_CONFIG_DROP}
+    if "cpu_baseline" in out:
+        out["cpu_baseline"] = dict(out["cpu_baseline"])
+        for k in ("compiler_flags", "unit"):
+            out["cpu_baseline"].pop(k, None)
+    return out
 
 
 def sharded_rank_cost(n_per_rank=125_000, world=8, ticks=600, latency_us=20.0, split=True, warm=80, volume_per_uav=64.0):
@@ -588,10 +639,88 @@ def sharded_rank_record(args):
     """sub-record of the default line: what one rank of an 8-rank config-5 run costs per tick at 10 and 20 us of collective latency
     (split form, and the serial form at 10 us) — the figures DESIGN §5 and BASELINE.md quote, reproducible from the driver's own run"""
     runs = [sharded_rank_cost(latency_us=10.0, ticks=400), sharded_rank_cost(latency_us=20.0, ticks=400), sharded_rank_cost(latency_us=10.0, ticks=400, split=False)]
-    return {"workload": "one rank (rank 4) of 8 x 125000 UAVs of BASELINE configs[4] alone on the GPU, stand-in collective of fixed latency with periodic-image "
-                        "neighbours (mrs_swarm_comm_init_standin): NOT a multi-GPU measurement",
-            "unit": "us per tick (wall clock over the call, 400 ticks incl. searches)",
-            "split_10us": runs[0]["us_per_tick"], "split_20us": runs[1]["us_per_tick"], "serial_10us": runs[2]["us_per_tick"], "runs": runs}
+    keep = ("split_ticks", "boundary_blocks", "blocks", "export_set", "searches", "replayed_noop_ticks")
+    return {"workload": "rank 4 of 8 x 125000 UAVs of BASELINE configs[4] alone on the GPU, fixed-latency stand-in collective: NOT a multi-GPU measurement",
+            "unit": "us per tick (wall clock, 400 ticks incl. searches)",
+            "split_10us": runs[0]["us_per_tick"], "split_20us": runs[1]["us_per_tick"], "serial_10us": runs[2]["us_per_tick"],
+            "split_run": {k: runs[0][k] for k in keep}, "serial_run": {k: runs[2][k] for k in keep}}
+
+
+def io_tick_record(args, n=100_000, ticks=150, warm=20):
+    """The headline workload with the host in the loop EVERY tick (the reference publishes every UAV's odometry / IMU /
+    range after every step, src/uav_system_ros.cpp:278-282, and its subscribers write commands at any time): a staged command block
+    up (n x 4 doubles), one makeStep, the packed publisher payload of every UAV down (n x 136 B).  serial: commit, step, synchronous
+    download, one after the other; pipelined: the download is started behind the step (mrs_swarm_get_outputs_async) and waited for
+    after the NEXT tick has been queued, copies on a stream of their own.  The rows are pre-filled (what the subscribers would write);
+    the payload is handed out, not read."""
+    import mrs_multirotor_simulator_amd as M
+    st, cmd = make_inputs(n, "actuator", seed=3)
+    sw = M.Swarm(n, arith=M.ARITH_FAST if args.arith == "fast" else M.ARITH_LITERAL)
+    sw.construct(0, n, M.model_params("x500", ground_enabled=True))
+    sw.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    for _ in range(2):  # both row blocks
+        sw.input_staging(n, 4)[:] = cmd
+        sw.commit_input(0, n, M.ACTUATOR_CMD, 4)
+    from mrs_multirotor_simulator_amd.swarm import OUTPUT_DTYPE
+    out_bytes, in_bytes = n * OUTPUT_DTYPE.itemsize, n * 4 * 8
+
+    def serial(k):
+        for _ in range(k):
+            sw.input_staging(n, 4)
+            sw.commit_input(0, n, M.ACTUATOR_CMD, 4)
+            sw.step(DT)
+            sw.get_outputs_view()
+
+    def pipelined(k):
+        pending = None
+        for _ in range(k):
+            sw.input_staging(n, 4)
+            sw.commit_input(0, n, M.ACTUATOR_CMD, 4)
+            sw.step(DT)
+            t = sw.get_outputs_async()
+            if pending is not None:
+                sw.outputs_wait(pending)
+            pending = t
+        sw.outputs_wait(pending)
+
+    res = {}
+    for name, fn in (("serial", serial), ("pipelined", pipelined)):
+        fn(warm)
+        sw.synchronize()
+        t0 = time.perf_counter()
+        fn(ticks)
+        sw.synchronize()
+        el = (time.perf_counter() - t0) / ticks
+        res[name] = {"ms_per_tick": el * 1e3, "value": n / el, "d2h_GBps": out_bytes / el / 1e9, "pcie_GBps_both_ways": (out_bytes + in_bytes) / el / 1e9}
+    del sw
+    return {"workload": f"BASELINE configs[2] ({n} x500, actuator references) + per tick: staged command upload, full publisher payload download",
+            "unit": "UAV-steps/s", "ticks": ticks, "bytes_down_per_tick": out_bytes, "bytes_up_per_tick": in_bytes,
+            "serial": res["serial"], "pipelined": res["pipelined"], "speedup": res["serial"]["ms_per_tick"] / res["pipelined"]["ms_per_tick"]}
+
+
+def _gloo_allgather(R):
+    """mrs_allgather_fn over the run's gloo group (rehearsal only): the launches queued so far finish, the bytes cross the processes"""
+    import ctypes as C
+    torch, dist = R.torch, R.dist
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def allgather(user, send, recv, nbytes, stream):
+        try:
+            if hip.hipStreamSynchronize(stream):
+                return 1
+            mine = np.empty(nbytes, dtype=np.uint8)
+            if hip.hipMemcpy(mine.ctypes.data, send, nbytes, 2):  # device -> host
+                return 1
+            everyone = torch.empty(R.world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(everyone, torch.from_numpy(mine))
+            return hip.hipMemcpy(recv, everyone.numpy().ctypes.data, R.world * nbytes, 1)  # host -> device
+        except Exception as e:  # noqa: BLE001 - a lost peer: the library turns the status into MRS_ERR_*, the leg into config5.error
+            sys.stderr.write(f"bench.py: rehearsal all-gather failed: {type(e).__name__}: {e}\n")
+            return 1
+
+    return allgather
 
 
 def config5_leg(args, R):
@@ -612,11 +741,17 @@ def config5_leg(args, R):
     sw.set_state(0, n, st["x"][own], st["v"][own], st["R"][own], st["omega"][own], st["motor_rpm"][own])
     sw.set_input(0, n, M.POSITION_CMD, cmd[own])
     del st, cmd
+    transport = args.config5_transport if R.use_dist else "rccl"
     if args.config5_transport == "peer" and R.use_dist:
         _, handle = sw.peer_window_create(R.world, R.rank, n_total)
         handles = [None] * R.world
         dist.all_gather_object(handles, handle)
         sw.comm_init_peer(handles=handles)
+    elif R.rehearsal:
+        # rehearsal: RCCL refuses two ranks on one device — the collective is the caller-supplied one of the C ABI
+        # (mrs_swarm_comm_init_custom): device -> host -> gloo all_gather -> device, blocking (tests/test_sharded_multiprocess_gpu.py)
+        transport = "host all-gather over gloo (rehearsal)"
+        sw.comm_init_custom(R.world, R.rank, n_total, _gloo_allgather(R))
     else:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if R.rank == 0:
@@ -636,20 +771,22 @@ def config5_leg(args, R):
     # regions of at least 200 ticks: a search comes every ~28 ticks and a call starts with two ticks in the serial form, so
     # the driver's K = 20 would time the start-up of a call, not the tick
     steps, warmup = max(args.steps, 200), min(max(args.warmup, 30), 60)
+    if os.environ.get("MRS_BENCH_KILL_RANK") == str(R.rank) and R.world > 1:  # test hook: this rank is lost inside the leg
+        run(warmup)
+        os.kill(os.getpid(), 9)
     times, _ = timed_regions(R, run, sync_local, steps, warmup, args.min_measure_ms)
     el = float(np.median(times))
     info = sw.comm_info()
     ticks, searches = sw.collision_stats()
-    out = {"workload": f"BASELINE configs[4]: {n_total} x500 UAVs, position references + mutual collisions (64 m^3 per UAV), {R.world} shards",
+    out = {"workload": f"BASELINE configs[4]: {n_total} x500 UAVs, position references + collisions, {R.world} shard(s)",
            "value": n_total * steps / el, "unit": "UAV-steps/s", "ms_per_tick": el / steps * 1e3, "n_total": n_total, "n_gpus": R.world,
            "steps": steps, "warmup": warmup, "regions": len(times), "scaling": "strong",
            "parallelism": info["parallelism"], "rccl_ranks": info["rccl_ranks"],
-           "transport": args.config5_transport if R.use_dist else "rccl",
+           "transport": transport, "n_devices": 1 if R.rehearsal else R.world,
            "shards": args.config5_shards,
            "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collective_bytes_per_rank_per_search_tick": info["bytes_per_rebuild"],
            "export_set_of_rank0": info["export_count"], "export_capacity": info["export_capacity"], "uavs_per_rank": n,
-           "sharded_ticks": info["ticks"], "search_ticks": info["searches"], "replayed_noop_ticks": info["noop_ticks"],
-           "collision_ticks": int(ticks), "neighbour_searches": int(searches)}
+           "sharded_ticks": info["ticks"], "search_ticks": info["searches"], "replayed_noop_ticks": info["noop_ticks"]}
     if R.use_dist:
         dist.barrier()  # (peer windows: nobody unmaps a window a peer may still write into)
     sw.comm_destroy()
@@ -690,6 +827,9 @@ def peer_leg_in_children(args):
 
 def main():
     args = parse()
+    if args.explain:
+        print(json.dumps(NOTES, indent=1))
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     # stdout carries the ONE JSON line and nothing else: libraries that print banners there (RCCL's version block) go to stderr
@@ -751,6 +891,7 @@ def main():
         rec, _, _ = step_leg(args, R, 400, "config2", 2000, 200, min_ms=30.0, airframe="f550", substeps=10)
         out["config2"]["fused_10_substeps_per_launch"] = {k: rec[k] for k in ("value", "ms_per_step", "device_ms_per_step")}
         out["sharded_rank_standin"] = sharded_rank_record(args)
+        out["io_tick"] = io_tick_record(args)
 
     import threading
     emit_lock, emitted = threading.Lock(), []
@@ -766,7 +907,11 @@ def main():
             sys.stdout.flush()
             os.dup2(json_fd, 1)
             if R.rank == 0:
-                print(json.dumps(out), flush=True)
+                out["notes"] = "python bench.py --explain; DESIGN.md 6"
+                if R.rehearsal:
+                    out["rehearsal"] = "MRS_BENCH_REHEARSAL=1: every rank on cuda:0, gloo process group — code path only, NOT a multi-GPU measurement"
+                    out["n_devices"] = 1
+                print(json.dumps(compact_line(out)), flush=True)
             return True
 
     if args.config5 == "on" or (args.config5 == "auto" and not args.pmc_child and args.workload == "actuator"):
@@ -782,6 +927,23 @@ def main():
         watchdog = threading.Timer(args.config5_timeout, give_up, args=(f"no result within {args.config5_timeout:.0f} s",))
         watchdog.daemon = True
         watchdog.start()
+        if R.world > 1:
+            # torch.distributed.run answers a failed rank by sending SIGTERM to the others (SIGKILL 30 s later).  The main thread
+            # may sit in a collective or a synchronize (no Python signal handler runs there): the C-level handler writes the signal
+            # number into a pipe, a thread reads it and prints the headline line with the failure recorded
+            import signal
+            rd, wr = os.pipe()
+            os.set_blocking(wr, False)
+            signal.set_wakeup_fd(wr, warn_on_full_buffer=False)
+            signal.signal(signal.SIGTERM, lambda *_: None)
+
+            def on_signal():
+                while True:
+                    b = os.read(rd, 1)
+                    if b and b[0] == signal.SIGTERM:
+                        give_up("terminated by the launcher while the config-5 leg was running (another rank was lost)")
+
+            threading.Thread(target=on_signal, daemon=True).start()
         try:
             c5 = config5_leg(args, R)
         except Exception as e:  # noqa: BLE001 - recorded in the line, the other ranks run into their own timeout

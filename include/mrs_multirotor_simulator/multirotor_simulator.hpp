@@ -13,6 +13,10 @@
 //     the safe command of its mode (timeoutInput) and the stamp is cleared; the model is iterated only
 //     if (iterate_without_input || time_last_input > 0)                            (src/uav_system_ros.cpp:243-271)
 //   * spawn randomisation `randd`                                                  (src/uav_system_ros.cpp:89-94, 653-658)
+//   * publishers: every UAV's odometry / IMU / range after its step (src/uav_system_ros.cpp:278-282) and the pose array every
+//     tick (src/multirotor_simulator.cpp:215, 365-389) — here ONE packed download per tick, started behind the tick's launch and
+//     handed to the publisher callback while the NEXT tick runs (mrs_swarm_get_outputs_async): messages leave one tick late in
+//     wall time, stamped with the sim time of the tick they describe
 // Time is kept in integer nanoseconds like ros::Time.  "now" for the watchdog is the last PUBLISHED clock value: the
 // reference's callbacks read ros::Time::now(), which under use_sim_time is the /clock message this very node sent last.
 //
@@ -24,7 +28,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace mrs_multirotor_simulator {
@@ -57,10 +64,20 @@ inline void randomizeSpawn(double bounds_x, double bounds_y, double bounds_z, do
   heading += randd(-3.14, 3.14);
 }
 
+namespace detail {
+// does the swarm type offer the pipelined publisher download (UavSwarm does; the GPU-less test doubles need not)
+template <class S, class = void>
+struct has_async_outputs : std::false_type {};
+template <class S>
+struct has_async_outputs<S, std::void_t<decltype(std::declval<S&>().outputsWait(std::declval<S&>().getOutputsAsync(0, 0)))>> : std::true_type {};
+}  // namespace detail
+
 template <class SwarmT>
 class BasicMultirotorSimulator {
 public:
   using ns_t = int64_t;
+  // publisher callback: (sim time of the tick the payload describes, packed payloads of all UAVs — mrs_uav_output_t[count] —, count)
+  using PublishFn = std::function<void(double, const void*, int)>;
 
   BasicMultirotorSimulator(SwarmT& swarm, int n_uavs, const SimulatorConfig& cfg, double sim_time_start = 0.0)
       : swarm_(swarm), cfg_(cfg), n_(n_uavs), time_last_input_((size_t)n_uavs, 0) {
@@ -80,12 +97,35 @@ public:
     if (oldest_input_ == 0 || t < oldest_input_) oldest_input_ = t;
   }
 
+  // ---- publishers (src/uav_system_ros.cpp:278-282, src/multirotor_simulator.cpp:215): fn gets every tick's payload, one tick late ----
+  void setPublisher(PublishFn fn) { publish_ = std::move(fn); }
+  // hand out the payload of the last tick (end of a run, before a pause: nothing stays in flight)
+  void flushPublisher() {
+    if constexpr (detail::has_async_outputs<SwarmT>::value) {
+      if (pending_ticket_ >= 0 && publish_) {
+        int count = 0;
+        const void* v = swarm_.outputsWait(pending_ticket_, &count);
+        publish_(toSec(pending_time_), v, count);
+      }
+      pending_ticket_ = -1;
+    }
+  }
+
   // ---- timerMain (src/multirotor_simulator.cpp:198-230): one tick; true when a clock message is due ----
   bool timerMain() {
     const double step = 1.0 / cfg_.simulation_rate;
     sim_time_ += toNs(step);
     checkInputTimeouts();                                                                  // UavSystemRos::makeStep, first half
     swarm_.makeStep(step);                                                                 // :211-213
+    if constexpr (detail::has_async_outputs<SwarmT>::value) {                              // :215 publishPoses (+ uav_system_ros.cpp:278-282)
+      if (publish_ && n_ > 0) {
+        const int ticket = swarm_.getOutputsAsync(0, n_);  // behind this tick's launch; the copy runs beside the next tick
+        const ns_t stamp = sim_time_;
+        flushPublisher();                                  // the PREVIOUS tick's payload: landed while this tick was being queued
+        pending_ticket_ = ticket;
+        pending_time_   = stamp;
+      }
+    }
     swarm_.handleCollisions(cfg_.collisions_enabled, cfg_.collisions_crash, cfg_.collisions_rebounce);  // :217
     ticks_++;
     if (toSec(sim_time_ - last_published_time_) >= (1.0 / cfg_.clock_rate) * (1.0 - 1e-6)) {  // :221
@@ -195,6 +235,9 @@ private:
   ns_t              sim_time_ = 0, last_published_time_ = 0, last_sim_time_status_ = 0;
   double            actual_rtf_ = 1.0;  // multirotor_simulator.cpp:62
   int64_t           ticks_      = 0;
+  PublishFn         publish_;
+  int               pending_ticket_ = -1;
+  ns_t              pending_time_   = 0;
 };
 
 }  // namespace mrs_multirotor_simulator

@@ -699,6 +699,20 @@ public:
     mrs_throw_on_error(mrs_swarm_get_outputs_view(s_, first, count, &v));
     return v;
   }
+  // the same PIPELINED with the steps (mrs_swarm_get_outputs_async / mrs_swarm_outputs_wait): start the download behind the steps
+  // queued so far, wait for it later — after the next tick has been queued — and publish while that tick runs
+  int getOutputsAsync(int first, int count) {
+    int32_t ticket = -1;
+    mrs_throw_on_error(mrs_swarm_get_outputs_async(s_, first, count, &ticket));
+    return ticket;
+  }
+  const mrs_uav_output_t* outputsWait(int ticket, int* count = nullptr) {
+    const mrs_uav_output_t* v = nullptr;
+    int32_t                 c = 0;
+    mrs_throw_on_error(mrs_swarm_outputs_wait(s_, ticket, &v, &c));
+    if (count) *count = c;
+    return v;
+  }
   // batched subscriber side: pinned rows to fill with setInput payloads (layout of mrs_swarm_set_input), then one commit
   double* inputStaging(int count, int stride) {
     double* rows = nullptr;

@@ -152,8 +152,9 @@ int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mo
 /* Staged form of mrs_swarm_set_input for hosts that refresh every command each tick (the subscriber callbacks of
  * src/uav_system_ros.cpp:679-1022, batched): mrs_swarm_input_staging hands out pinned host memory for count rows of `stride`
  * doubles (row k = the setInput payload of UAV first+k, layouts as above); the caller fills it and mrs_swarm_commit_input sends it
- * with one asynchronous copy + one unpack kernel — no pageable staging, no per-column copies.  The rows may be refilled after the
- * next mrs_swarm_input_staging call (which waits for the copy in flight). */
+ * with one asynchronous copy (on a copy stream, beside the running step) + one unpack kernel on the swarm's stream — no pageable
+ * staging, no per-column copies.  Two row blocks are handed out in turn: a block returned by mrs_swarm_input_staging belongs to
+ * the caller until the commit that follows; the call waits only for the COPY of the commit two calls back, never for a step. */
 int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, double** rows);
 int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, int32_t stride);
 
@@ -233,6 +234,17 @@ int mrs_swarm_get_outputs(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_
 /* the same payloads without the final host copy: *view points into the library's pinned staging buffer and stays valid until the
  * next mrs_swarm_get_outputs* call on this swarm (publishers fill their messages straight from it) */
 int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, const mrs_uav_output_t** view);
+/* The same payloads PIPELINED with the steps — what a loop that publishes every UAV's odometry / IMU / range every step
+ * (src/uav_system_ros.cpp:278-282) and the pose array every tick (src/multirotor_simulator.cpp:215,365-389) should call.
+ * mrs_swarm_get_outputs_async returns at once: the pack kernel is queued on the swarm's stream behind every step queued so far, the
+ * device-to-host copy runs on a copy stream into one of two pinned blocks.  mrs_swarm_outputs_wait blocks until THAT copy has
+ * landed (an event, not a stream synchronisation: steps queued after the _async call keep running — the download of tick t overlaps
+ * step t + 1) and hands out the block; it stays valid until the second _async call after this ticket's.  At most two tickets are in
+ * flight.  Collision ticks evaluated lazily by the next step launch (mrs_swarm_tick_n) stay lazy: if a launch before the pack turned
+ * out to be a no-op (stale neighbour lists), the wait repeats search, launches and pack before it returns — the payload is always
+ * the state after the tick the caller packed behind. */
+int mrs_swarm_get_outputs_async(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* ticket);
+int mrs_swarm_outputs_wait(mrs_swarm_t* s, int32_t ticket, const mrs_uav_output_t** view, int32_t* count);
 
 /* ---- multi-GPU collision exchange (one swarm shard per process/GPU) ---- */
 /* device pointer + byte size of this shard's packed {x,y,z,mass,arm_length,prop_radius} records (48 B/UAV), refreshed by

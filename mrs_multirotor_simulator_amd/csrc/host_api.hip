@@ -540,8 +540,19 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->dSt) (void)hipFree(s->dSt);
   if (s->hSt) (void)hipHostFree(s->hSt);
   if (s->hOut) (void)hipHostFree(s->hOut);
-  if (s->hIn) (void)hipHostFree(s->hIn);
-  if (s->dIn) (void)hipFree(s->dIn);
+  for (auto& o : s->oslot) {
+    if (o.d) (void)hipFree(o.d);
+    if (o.h) (void)hipHostFree(o.h);
+    if (o.packed) (void)hipEventDestroy(o.packed);
+    if (o.done) (void)hipEventDestroy(o.done);
+  }
+  for (auto& i : s->islot) {
+    if (i.d) (void)hipFree(i.d);
+    if (i.h) (void)hipHostFree(i.h);
+    if (i.copied) (void)hipEventDestroy(i.copied);
+    if (i.unpacked) (void)hipEventDestroy(i.unpacked);
+  }
+  if (s->stream_io) (void)hipStreamDestroy(s->stream_io);
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
@@ -1094,6 +1105,83 @@ int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, con
   return MRS_OK;
 }
 
+}  // extern "C"
+namespace mrs_host {
+static int ensure_io_stream(mrs_swarm* s) {
+  if (!s->stream_io) HIPCHK(hipStreamCreateWithFlags(&s->stream_io, hipStreamNonBlocking));
+  return MRS_OK;
+}
+// pack behind everything queued on the step stream, copy on the copy stream (also called by drain() when the launch the pack
+// followed is replayed after a stall)
+int issue_outputs(mrs_swarm* s, int slot) {
+  mrs_swarm::OutSlot& o = s->oslot[slot];
+  HIPCHK(hipStreamWaitEvent(s->stream, o.done, 0));  // the copy out of this buffer two tickets ago (a no-op when long complete)
+  HIPCHK(mrs_launch_pack_outputs(s->view(), o.first, o.count, o.d, s->stream));
+  HIPCHK(hipEventRecord(o.packed, s->stream));
+  HIPCHK(hipStreamWaitEvent(s->stream_io, o.packed, 0));
+  HIPCHK(hipMemcpyAsync(o.h, o.d, sizeof(mrs_uav_output_t) * (size_t)o.count, hipMemcpyDeviceToHost, s->stream_io));
+  HIPCHK(hipEventRecord(o.done, s->stream_io));
+  return MRS_OK;
+}
+}  // namespace mrs_host
+extern "C" {
+
+int mrs_swarm_get_outputs_async(mrs_swarm_t* s, int32_t first, int32_t count, int32_t* ticket) {
+  MRS_LOCK(s);  // NOT settle(): launches of lazily evaluated collision ticks stay queued; a stall among them is put right at the wait
+  int rc = check_range(s, first, count);
+  if (rc) return rc;
+  if (!ticket) return fail(MRS_ERR_ARG, "null ticket");
+  if (count == 0) return fail(MRS_ERR_ARG, "empty range");
+  HIPCHK(hipSetDevice(s->device));
+  if ((rc = upload_types(s, s->table_dt > 0 ? s->table_dt : 0.001))) return rc;
+  if ((rc = ensure_io_stream(s))) return rc;
+  const int32_t        t = s->out_tickets;
+  mrs_swarm::OutSlot&  o = s->oslot[t & 1];
+  if (!o.packed) {
+    HIPCHK(hipEventCreateWithFlags(&o.packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&o.done, hipEventDisableTiming));
+  }
+  if (count > o.cap) {
+    HIPCHK(hipEventSynchronize(o.done));  // (nobody copies out of the old buffer any more)
+    if (o.d) HIPCHK(hipFree(o.d));
+    if (o.h) HIPCHK(hipHostFree(o.h));
+    o.d = nullptr; o.h = nullptr; o.cap = 0;
+    HIPCHK(hipMalloc(&o.d, sizeof(mrs_uav_output_t) * (size_t)count));
+    HIPCHK(hipHostMalloc(&o.h, sizeof(mrs_uav_output_t) * (size_t)count, hipHostMallocDefault));
+    o.cap = count;
+  }
+  o.ticket = t;
+  o.first  = first;
+  o.count  = count;
+  if ((rc = issue_outputs(s, t & 1))) return rc;
+  if (!s->log.empty()) s->log.back().out_ticket = t;  // the pack followed this launch: a replay of it repeats the pack
+  s->out_tickets++;
+  *ticket = t;
+  return MRS_OK;
+}
+
+int mrs_swarm_outputs_wait(mrs_swarm_t* s, int32_t ticket, const mrs_uav_output_t** view, int32_t* count) {
+  MRS_LOCK(s);
+  if (!s || !view) return fail(MRS_ERR_ARG, "null argument");
+  *view = nullptr;
+  if (ticket < 0 || ticket >= s->out_tickets) return fail(MRS_ERR_ARG, "no such ticket");
+  mrs_swarm::OutSlot& o = s->oslot[ticket & 1];
+  if (o.ticket != ticket) return fail(MRS_ERR_ARG, "this ticket's block has been handed to a newer download (two downloads in flight at most)");
+  HIPCHK(hipSetDevice(s->device));
+  for (;;) {
+    HIPCHK(hipEventSynchronize(o.done));  // that copy only: steps queued behind the pack keep running
+    // launches of lazily evaluated collision ticks may have turned into no-ops before the pack ran (a UAV left its skin: DESIGN §4 K1b);
+    // drain() repeats the search, replays them — and re-issues every pack that followed a replayed launch
+    const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
+    if (s->log.empty() || !hw || hw[CTL_STALL] == 0u) break;
+    int rc = drain(s);
+    if (rc) return rc;
+  }
+  *view = o.h;
+  if (count) *count = o.count;
+  return MRS_OK;
+}
+
 int mrs_swarm_get_states(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_state_t* out) {
   MRS_ENTER(s);
   int rc = check_range(s, first, count);
@@ -1121,22 +1209,30 @@ int mrs_swarm_get_states(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_s
 }
 
 int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, double** rows) {
-  MRS_ENTER(s);
+  MRS_LOCK(s);
   if (!s || !rows) return fail(MRS_ERR_ARG, "null argument");
   if (count < 0 || count > s->n || stride < 1 || stride > 16) return fail(MRS_ERR_ARG, "bad staging shape");
   HIPCHK(hipSetDevice(s->device));
+  int rc = ensure_io_stream(s);
+  if (rc) return rc;
   const int64_t need = (int64_t)count * stride;
-  HIPCHK(hipStreamSynchronize(s->stream));  // an earlier commit may still be reading the rows
-  if (need > s->in_cap) {
-    if (s->hIn) HIPCHK(hipHostFree(s->hIn));
-    if (s->dIn) HIPCHK(hipFree(s->dIn));
-    s->hIn = nullptr;
-    s->dIn = nullptr;
-    HIPCHK(hipHostMalloc(&s->hIn, sizeof(double) * (size_t)need, hipHostMallocDefault));
-    HIPCHK(hipMalloc(&s->dIn, sizeof(double) * (size_t)need));
-    s->in_cap = need;
+  s->in_turn ^= 1;  // the other block: the commit of the previous one may still be copying
+  mrs_swarm::InSlot& b = s->islot[s->in_turn];
+  if (!b.copied) {
+    HIPCHK(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b.unpacked, hipEventDisableTiming));
   }
-  *rows = s->hIn;
+  HIPCHK(hipEventSynchronize(b.copied));  // the commit two calls ago has read these rows (that copy only: no stream is waited for)
+  if (need > b.cap) {
+    HIPCHK(hipEventSynchronize(b.unpacked));
+    if (b.h) HIPCHK(hipHostFree(b.h));
+    if (b.d) HIPCHK(hipFree(b.d));
+    b.h = nullptr; b.d = nullptr; b.cap = 0;
+    HIPCHK(hipHostMalloc(&b.h, sizeof(double) * (size_t)need, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&b.d, sizeof(double) * (size_t)need));
+    b.cap = need;
+  }
+  *rows = b.h;
   return MRS_OK;
 }
 
@@ -1146,7 +1242,8 @@ int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t
   if (rc) return rc;
   if (mode < MRS_ACTUATOR_CMD || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
   if (count == 0) return MRS_OK;
-  if (!s->hIn || (int64_t)count * stride > s->in_cap) return fail(MRS_ERR_ARG, "no staging rows of this shape (call mrs_swarm_input_staging first)");
+  mrs_swarm::InSlot& b = s->islot[s->in_turn];
+  if (!b.h || (int64_t)count * stride > b.cap) return fail(MRS_ERR_ARG, "no staging rows of this shape (call mrs_swarm_input_staging first)");
   int width = 4;
   if (mode == MRS_ACTUATOR_CMD) width = stride < MRS_MAX_MOTORS ? stride : MRS_MAX_MOTORS;
   if (mode == MRS_ATTITUDE_CMD) width = 10;
@@ -1157,8 +1254,13 @@ int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t
       if (s->keys[s->uav_type[(size_t)first + k]].mp.n_motors > width) return fail(MRS_ERR_ARG, "actuator payload narrower than n_motors");
   }
   HIPCHK(hipSetDevice(s->device));
-  HIPCHK(hipMemcpyAsync(s->dIn, s->hIn, sizeof(double) * (size_t)count * (size_t)stride, hipMemcpyHostToDevice, s->stream));
-  HIPCHK(mrs_launch_unpack_rows(s->view(), s->dIn, stride, width, F_CMD, first, count, s->stream));
+  // the copy runs on the copy stream (beside whatever step is running), the step stream takes it in where this call stands
+  HIPCHK(hipStreamWaitEvent(s->stream_io, b.unpacked, 0));  // the unpack kernel of this block's previous commit
+  HIPCHK(hipMemcpyAsync(b.d, b.h, sizeof(double) * (size_t)count * (size_t)stride, hipMemcpyHostToDevice, s->stream_io));
+  HIPCHK(hipEventRecord(b.copied, s->stream_io));
+  HIPCHK(hipStreamWaitEvent(s->stream, b.copied, 0));
+  HIPCHK(mrs_launch_unpack_rows(s->view(), b.d, stride, width, F_CMD, first, count, s->stream));
+  HIPCHK(hipEventRecord(b.unpacked, s->stream));
   track_mode(s, first, count, mode);
   return flags_update(s, first, count, ~FLAG_MODE_MASK, (uint32_t)mode << FLAG_MODE_SHIFT);
 }

@@ -231,10 +231,27 @@ struct mrs_swarm {
   mrs_uav_state_t*  dSt = nullptr;   // packed states (mrs_swarm_get_states): device buffer + pinned host staging
   mrs_uav_state_t*  hSt = nullptr;
   int32_t           st_cap = 0;
-  // staged command upload: pinned host rows + device copy
-  double* hIn = nullptr;
-  double* dIn = nullptr;
-  int64_t in_cap = 0;  // doubles
+  // Pipelined publisher download (mrs_swarm_get_outputs_async / mrs_swarm_outputs_wait): two pack buffers with a pinned block each;
+  // the pack kernel runs on the step stream behind everything queued so far, the device-to-host copy on `stream_io`, so the download
+  // of tick t overlaps step t + 1.  `packed` orders copy behind pack, `done` is what the host waits for (and what the next pack into
+  // the same buffer waits for on the device).
+  struct OutSlot {
+    mrs_uav_output_t *d = nullptr, *h = nullptr;
+    int32_t           cap = 0, ticket = -1, first = 0, count = 0;
+    hipEvent_t        packed = nullptr, done = nullptr;
+  };
+  OutSlot     oslot[2];
+  hipStream_t stream_io = nullptr;  // copies of the pipelined download and of the staged command upload
+  int32_t     out_tickets = 0;
+  // staged command upload: two pinned row blocks + device copies, handed out in turn — the caller fills block k + 1 while the copy of
+  // block k may still be in flight (`copied`: the host may refill the rows; `unpacked`: the device copy may be overwritten)
+  struct InSlot {
+    double *   h = nullptr, *d = nullptr;
+    int64_t    cap = 0;  // doubles
+    hipEvent_t copied = nullptr, unpacked = nullptr;
+  };
+  InSlot  islot[2];
+  int     in_turn = 0;   // the block the last mrs_swarm_input_staging handed out
   // collision scratch
   PosRecord*   dRec = nullptr;
   CollideWork* cwork = nullptr;
@@ -247,7 +264,9 @@ struct mrs_swarm {
   // leaves its skin during step T the launches after T turn into no-ops, and the host repeats the search and replays them.
   struct Collide { bool on = false; int enabled = 0, crash = 0; double rebounce = 0.0; };
   // one fused launch: the collision tick it evaluates first (searched: a search queued right before it has done that), then makeStep(dt)
-  struct TickRec { double dt; Collide eval; bool searched; int pin; };  // pin: which position buffer the launch read
+  // pin: which position buffer the launch read; out_ticket: a pipelined output download packed right behind this launch (re-issued
+  // when the launch is replayed after a stall: what it packed then was the state of an earlier tick)
+  struct TickRec { double dt; Collide eval; bool searched; int pin; int out_ticket = -1; };
   Collide              pend;                        // requested after the most recent step, not evaluated yet
   // A fused launch consumes the force it evaluates from registers and does not write the F_ext columns (24 B per UAV and tick).
   // While f_lazy.on those columns are stale: the latched force is "collision tick f_lazy on the position records f_lazy_pin",
@@ -314,6 +333,7 @@ int settle(mrs_swarm* s);
 
 namespace mrs_host {
 // ---- host_api.hip ----
+int     issue_outputs(mrs_swarm* s, int slot);  // pack + copy of the pipelined download held by oslot[slot]
 void    track_mode(mrs_swarm* s, int first, int count, int mode);
 int     check_range(const mrs_swarm* s, int first, int count);
 int     intern_type(mrs_swarm* s, const TypeKey& k, int* out);
@@ -333,6 +353,7 @@ int  finish_profile(mrs_swarm* s);
 int  collide_now(mrs_swarm* s, const mrs_swarm::Collide& c, bool force);
 int  wait_for_progress(mrs_swarm* s, const volatile unsigned* hw, unsigned index, int lead);
 int  step_one(mrs_swarm* s, double dt);
+int  drain(mrs_swarm* s);
 inline unsigned min_nonzero(unsigned a, unsigned b) { return a == 0u ? b : (b == 0u ? a : (a < b ? a : b)); }
 // the stall / warning index the host knows of: each chain of a split tick keeps mirrors of its own (one writer per word)
 inline unsigned stall_word(const volatile unsigned* hw) { return min_nonzero(hw[CTL_STALL], hw[CTL_STALL2]); }

@@ -264,6 +264,8 @@ int drain(mrs_swarm* s) {
         s->region_launches++;
         if ((rc = launch_part(s, e.dt, 1, 0, (s->n + 63) / 64, 1, s->stream))) return rc;
       }
+      // a pipelined output download packed behind the no-op took the state of an earlier tick: once more, behind the real launch
+      if (e.out_ticket >= 0 && s->oslot[e.out_ticket & 1].ticket == e.out_ticket && (rc = issue_outputs(s, e.out_ticket & 1))) return rc;
     }
     if (s->log.empty()) return MRS_OK;
   }
@@ -293,6 +295,8 @@ int step_one(mrs_swarm* s, double dt) {
   if (s->collide_since_step && s->use_lists && s->use_fused) {
     const volatile unsigned* hw = mrs_collide_host_words(s->cwork);
     if (hw && hw[CTL_STALL] != 0u && (rc = drain(s))) return rc;  // seen without synchronising: stop feeding no-ops
+    // (a caller that never looks at the swarm — ticks and pipelined downloads only — would let the log grow for ever)
+    if (s->log.size() >= 65536u && (rc = drain(s))) return rc;
     if (s->pend.on && !fused_usable(s) && (rc = settle(s))) return rc;  // first tick / after host writes: the pass on its own
     if (fused_usable(s)) {
       mrs_swarm::TickRec e{dt, s->pend, false};

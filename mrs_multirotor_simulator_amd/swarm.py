@@ -100,6 +100,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
     "mrs_swarm_debug_search_ms", "mrs_swarm_debug_neighbour_lists", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
+    "mrs_swarm_get_outputs_async", "mrs_swarm_outputs_wait",
 ]
 
 STATE_DTYPE = np.dtype([("x", "f8", 3), ("v", "f8", 3), ("v_prev", "f8", 3), ("R", "f8", (3, 3)), ("omega", "f8", 3), ("motor_rpm", "f8", 8),
@@ -286,6 +287,8 @@ def load_library():
         "mrs_swarm_copy_uavs": [vp, i32, vp, i32, i32],
         "mrs_swarm_step_range": [vp, i32, i32, f64],
         "mrs_swarm_get_states": [vp, i32, i32, vp],
+        "mrs_swarm_get_outputs_async": [vp, i32, i32, ip],
+        "mrs_swarm_outputs_wait": [vp, i32, C.POINTER(vp), ip],
     }
     for name, args in sig.items():
         if os.environ.get("MRS_SWARM_LIB") and not hasattr(L, name):
@@ -640,6 +643,21 @@ class Swarm:
             return np.zeros(0, dtype=OUTPUT_DTYPE)
         buf = (C.c_char * (count * OUTPUT_DTYPE.itemsize)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=OUTPUT_DTYPE, count=count)
+
+    def get_outputs_async(self, first=0, count=None):
+        """pipelined download: pack behind the steps queued so far, copy on a copy stream; returns a ticket for outputs_wait"""
+        count = self.n - first if count is None else count
+        t = C.c_int32()
+        _check(_lib.mrs_swarm_get_outputs_async(self._h, first, count, C.byref(t)))
+        return int(t.value)
+
+    def outputs_wait(self, ticket):
+        """blocks until the download of `ticket` has landed (steps queued since keep running); a structured-array VIEW of the pinned
+        block, valid until the second get_outputs_async call after the ticket's"""
+        ptr, cnt = C.c_void_p(), C.c_int32()
+        _check(_lib.mrs_swarm_outputs_wait(self._h, int(ticket), C.byref(ptr), C.byref(cnt)))
+        buf = (C.c_char * (cnt.value * OUTPUT_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=OUTPUT_DTYPE, count=cnt.value)
 
     def input_staging(self, count, stride):
         """pinned host rows (count x stride doubles) to be filled with setInput payloads and sent by commit_input"""

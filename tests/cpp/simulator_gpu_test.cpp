@@ -1,7 +1,9 @@
 // simulator_gpu_test.cpp — MultirotorSimulator (include/mrs_multirotor_simulator/multirotor_simulator.hpp) over the real UavSwarm:
 // the watchdog / hold logic of UavSystemRos::makeStep (src/uav_system_ros.cpp:243-271) end to end on the GPU.
 // Exit code 0 and "ok ..." lines on success.
+#include <cmath>
 #include <cstdio>
+#include <vector>
 #include <mrs_multirotor_simulator/multirotor_simulator.hpp>
 
 using namespace mrs_multirotor_simulator;
@@ -97,5 +99,51 @@ int main() {
   const auto cs = swarm.collisionStats();
   CHECK(cs.first == sim.ticks());
   std::printf("ok paced %lld ticks, rtf %.3f, %lld neighbour searches\n", (long long)dticks, sim.actualRtf(), (long long)cs.second);
+
+  // publishers (src/uav_system_ros.cpp:278-282, src/multirotor_simulator.cpp:215): every tick's payload arrives exactly once, one tick
+  // late, stamped with its own sim time, and equals what a synchronous getOutputs() sees right after that tick — checked on a twin
+  // swarm stepped in lock step (collisions on: the ticks stay lazily evaluated behind the pipelined download)
+  {
+    UavSwarm twin(n, -1, true);
+    twin.construct(0, n, mp, pos, hdg);
+    twin.warmUp();
+    UavSwarm pub(n, -1, true);
+    pub.construct(0, n, mp, pos, hdg);
+    pub.warmUp();
+    for (int u = 0; u < n; u++) {
+      reference::Position c;
+      c.position = Eigen::Vector3d(pos[(size_t)u](0) + 1.0, pos[(size_t)u](1) - 1.0, 11.0);
+      c.heading  = 0.3;
+      twin[u].setInput(c);
+      pub[u].setInput(c);
+    }
+    SimulatorConfig pc = cfg;
+    pc.iterate_without_input = true;
+    MultirotorSimulator psim(pub, n, pc);
+    std::vector<std::vector<mrs_uav_output_t>> want;
+    std::vector<double>                        stamps;
+    int                                        seen = 0, bad = 0;
+    psim.setPublisher([&](double t, const void* payload, int count) {
+      const mrs_uav_output_t* o = static_cast<const mrs_uav_output_t*>(payload);
+      if (count != n || seen >= (int)want.size() || std::fabs(t - stamps[(size_t)seen]) > 1e-12) bad++;
+      else
+        for (int u = 0; u < n; u++)
+          for (int j = 0; j < 3; j++)
+            if (o[u].position[j] != want[(size_t)seen][(size_t)u].position[j] || o[u].linear_acceleration[j] != want[(size_t)seen][(size_t)u].linear_acceleration[j]) bad++;
+      seen++;
+    });
+    const int pticks = 25;
+    for (int k = 0; k < pticks; k++) {
+      twin.makeStep(1.0 / pc.simulation_rate);
+      want.push_back(twin.getOutputs(0, n));
+      twin.handleCollisions(pc.collisions_enabled, pc.collisions_crash, pc.collisions_rebounce);
+      stamps.push_back(psim.simTime() + 1.0 / pc.simulation_rate);
+      psim.timerMain();
+      CHECK(seen == k);  // one tick late
+    }
+    psim.flushPublisher();
+    CHECK(seen == pticks && bad == 0);
+    std::printf("ok pipelined_publisher %d ticks\n", seen);
+  }
   return 0;
 }

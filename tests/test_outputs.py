@@ -113,3 +113,82 @@ def test_outputs_view_and_staged_input_equal_the_copying_calls(mrs, oracle):
             assert np.array_equal(oa[f], ov[f]), f"case {tick}: output {f}"
     with pytest.raises(Exception):
         b.commit_input(0, n, mrs.ATTITUDE_CMD, 4)   # stride too small for the mode
+
+
+@pytest.mark.gpu
+def test_pipelined_outputs_equal_the_synchronous_ones_while_steps_run(mrs, oracle):
+    """mrs_swarm_get_outputs_async / mrs_swarm_outputs_wait: the download of tick t is waited for AFTER tick t + 1 has
+    been queued — staged commands every tick through the two row blocks, two tickets in flight — and must be the payload a
+    synchronous mrs_swarm_get_outputs returns right after tick t on a twin swarm; the twin's final state equals the pipelined one."""
+    rng = np.random.default_rng(17)
+    n = 20_000
+    a, b = mrs.Swarm(n, arith=mrs.ARITH_FAST), mrs.Swarm(n, arith=mrs.ARITH_FAST)
+    st = scenario(oracle, rng, n)
+    for g in (a, b):
+        g.construct(0, n, mrs.model_params("x500", ground_enabled=True, ground_z=0.0))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+    ticks = 12
+    cmds = rng.uniform(0.35, 0.6, (ticks, n, 4))
+    want = []
+    for t in range(ticks):  # the serial loop: upload, step, download, one after the other
+        a.set_input(0, n, mrs.ACTUATOR_CMD, cmds[t])
+        a.step(0.001)
+        want.append(a.get_outputs().copy())
+    pending = None
+    for t in range(ticks):  # the pipelined loop
+        rows = b.input_staging(n, 4)
+        rows[:] = cmds[t]
+        b.commit_input(0, n, mrs.ACTUATOR_CMD, 4)
+        b.step(0.001)
+        ticket = b.get_outputs_async()
+        if pending is not None:  # tick t is in flight while tick t - 1 is read
+            got = b.outputs_wait(pending[1])
+            for f in got.dtype.names:
+                assert np.array_equal(got[f], want[pending[0]][f]), f"tick {pending[0]}: {f}"
+        pending = (t, ticket)
+    got = b.outputs_wait(pending[1])
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[ticks - 1][f]), f"last tick: {f}"
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    sub = b.outputs_wait(b.get_outputs_async(100, 50))  # a sub-range, waited for at once
+    assert np.array_equal(sub["position"], want[-1]["position"][100:150])
+    with pytest.raises(Exception):
+        b.outputs_wait(pending[1] - 1)  # that block has long been handed to a newer download
+
+
+@pytest.mark.gpu
+def test_pipelined_outputs_survive_a_stall_of_the_lazy_collision_ticks(mrs, oracle):
+    """With collisions on, mrs_swarm_tick_n leaves every tick to the NEXT launch and never synchronises; a launch whose lists went
+    stale turns the launches behind it into no-ops — and a pack queued behind a no-op has packed an older state.  The wait must
+    notice, replay and pack again: every pipelined payload equals the synchronous one of a twin swarm, stalls included."""
+    import bench
+    n = 20_000
+    st, cmd = bench.make_inputs(n, "position+collisions", seed=11, volume_per_uav=16.0)
+    # a few UAVs that cross the last quarter of their skin (0.0625 m) within ONE step: no warning can come in time, the launch after
+    # finds its lists stale whatever the host's pace (stall + replay every few ticks)
+    st["v"][:8] = [0.0, 70.0, 0.0]
+    a, b = mrs.Swarm(n, arith=mrs.ARITH_FAST), mrs.Swarm(n, arith=mrs.ARITH_FAST)
+    for g in (a, b):
+        g.construct(0, n, mrs.model_params("x500", ground_enabled=True, ground_z=0.0))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        g.set_input(0, n, mrs.POSITION_CMD, cmd)
+    ticks, pending, worst = 60, None, 0.0
+    for t in range(ticks):
+        a.tick_n(0.001, 1, True, False, 100.0)
+        want = a.get_outputs().copy()  # (settles the twin: search / evaluation on their own every tick)
+        b.tick_n(0.001, 1, True, False, 100.0)
+        ticket = b.get_outputs_async()
+        if pending is not None:
+            got = b.outputs_wait(pending[1])
+            for f in got.dtype.names:
+                worst = max(worst, helpers.rel_linf(got[f], pending[2][f]))
+                helpers.assert_close(got[f], pending[2][f], 1e-9, f"tick {pending[0]}: {f}")
+        pending = (t, ticket, want)
+    got = b.outputs_wait(pending[1])
+    for f in got.dtype.names:
+        helpers.assert_close(got[f], pending[2][f], 1e-9, f"last tick: {f}")
+    fused, stalls, replayed, ahead = b.fused_stats()
+    print(f"pipelined outputs with lazy collision ticks: {fused} fused launches, {stalls} stalls, {replayed} replayed launches, worst relative difference {worst:.2e}")
+    assert fused >= ticks // 2 and stalls >= 1 and replayed >= 1, (fused, stalls, replayed)  # the case the test is about has happened

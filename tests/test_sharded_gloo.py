@@ -1,6 +1,10 @@
-"""world_size-2 `gloo` tests (CPU) of the multi-GPU collision exchange: shard ranges, padded all-gather layout, and that
-shard-local collision results equal the single-process result.  The local engine here is the CPU oracle (test
-infrastructure) behind the same three calls the GPU engine implements."""
+"""world_size-2 `gloo` tests (CPU) of the multi-GPU collision exchange — LAYOUT ONLY: shard ranges, the padded all-gather layout of
+the Python orchestrator (mrs_multirotor_simulator_amd/sharded.py) and that shard-local collision results equal the single-process
+result.  The local engine here is the CPU oracle (test infrastructure) behind the same three calls the GPU engine implements, so
+this file does NOT exercise mrs_swarm_tick_sharded_n.  The library's own protocol is covered elsewhere: its host decisions
+(csrc/sharded_protocol.h) on a multi-rank CPU model under random host skew in tests/test_sharded_protocol.py, the whole protocol in
+separate PROCESSES on the GPU box in tests/test_sharded_multiprocess_gpu.py / test_peer_window_gpu.py / test_sharded_chaos_gpu.py,
+and bench.py's N > 1 path end to end in tests/test_bench_rehearsal_gpu.py."""
 import os
 import sys
 

@@ -94,10 +94,11 @@ def test_simulator_over_the_swarm_compiles(mrs):
 
 @pytest.mark.gpu
 def test_simulator_over_the_swarm_on_gpu(mrs):
-    """MultirotorSimulator<UavSwarm>: frozen without input, only commanded UAVs move, timeout -> hover command + hold, pacing."""
+    """MultirotorSimulator<UavSwarm>: frozen without input, only commanded UAVs move, timeout -> hover command + hold, pacing, and the
+    pipelined publisher (every tick's payload once, one tick late, equal to the synchronous download of a twin swarm)."""
     out = subprocess.run([_build_cpp(mrs, "simulator_gpu_test")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    for tag in ("frozen_without_input", "only_commanded_uavs_move", "timeout_puts_on_hold", "paced"):
+    for tag in ("frozen_without_input", "only_commanded_uavs_move", "timeout_puts_on_hold", "paced", "pipelined_publisher"):
         assert f"ok {tag}" in out.stdout, out.stdout
 
 
