@@ -168,7 +168,7 @@ def live_traffic(args, uavs=None, workload=None):
             return None, f"rocprofv3 --pmc {ctr}: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 64 steps"
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "live rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in separate passes)"
 
 
 def parse():
@@ -307,7 +307,7 @@ def cpu_baseline(args, st, cmd, workload=None, uavs=None, airframe="x500", secon
         if el > seconds:
             break
     out = {"value": n * steps / el, "unit": "UAV-steps/s", "cores": 1, "kind": "port", "compiler_flags": "gcc " + flags,
-           "sample": f"{n} {airframe} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c, 1 thread (the reference's loop is serial)"}
+           "sample": f"{n} {airframe} UAVs x {steps} steps of the same workload, oracle/uav_oracle.c, 1 thread"}
     if coll and O.ref_lib() is not None:
         # the reference's OWN broadphase on the same positions: nanoflann build + one radius search per UAV
         # (oracle/_ref, compiled from the reference tree) — "kind": "reference" for this part of the tick
@@ -319,7 +319,7 @@ def cpu_baseline(args, st, cmd, workload=None, uavs=None, airframe="x500", secon
             reps += 1
         ms = (time.perf_counter() - t0) / reps * 1e3
         out["collision_broadphase_reference"] = {"kind": "reference", "ms_per_tick": ms, "uavs": n, "us_per_uav_tick": ms * 1e3 / n,
-                                                 "sample": f"the reference's own nanoflann (oracle/_ref): build + {n} radius searches, 1 thread"}
+                                                 "sample": f"the reference's own nanoflann (oracle/_ref): build + {n} radius searches"}
     if not coll and workload != "config2":  # generous upper bound for a CPU implementation: pthreads over UAVs on every host core
         cores = os.cpu_count() or 1
         k, t0 = 0, time.perf_counter()
@@ -509,10 +509,9 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
         if workload == "actuator":
             wl = f"BASELINE configs[2]: {n} {airframe} UAVs per GPU, {workload} references, dt=1 ms, RK4, ground on"
         elif workload == "config2":
-            wl = (f"BASELINE configs[1]: {n} {airframe} hexarotors (tmux/standalone_400_uavs: 20 x 20 grid, 4 m pitch), position references "
-                  "(goto.py goals), no collisions, dt=1 ms")
+            wl = f"BASELINE configs[1]: {n} {airframe} on the tmux/standalone_400_uavs grid, position references (goto.py goals), dt=1 ms"
         elif coll:
-            wl = f"BASELINE configs[3]: {n} {airframe} UAVs, position references + mutual collisions + ground plane, {args.volume_per_uav:g} m^3 per UAV, dt=1 ms"
+            wl = f"BASELINE configs[3]: {n} {airframe} UAVs, position references + collisions + ground, {args.volume_per_uav:g} m^3 per UAV, dt=1 ms"
         else:
             wl = f"{n} {airframe} UAVs per GPU, {workload}, dt=1 ms"
         out = {
@@ -527,12 +526,8 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
             # Cache the operative limit is that cache, not HBM: `bound` says so, and the guide's measured lower bound for it is given
             "roofline": {"bound": "infinity-cache" if resident else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
-                         "regime": "infinity-cache-resident" if resident else "hbm-streaming",
-                         "peak_by_regime": {"hbm-streaming": HBM_PEAK_GBS, "infinity-cache-resident": INFINITY_CACHE_GBS},
-                         "frac_of_regime_peak": achieved / (INFINITY_CACHE_GBS if resident else HBM_PEAK_GBS),
-                         "touched_bytes": touched,
+                         "infinity_cache_peak": INFINITY_CACHE_GBS, "touched_bytes": touched,
                          "bytes_moved_per_uav_step": b_mov, "moved_GBps": moved,
-                         "frac_moved_of_peak": moved / HBM_PEAK_GBS,
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": moved / HBM_ACHIEVABLE_GBS,
                          "kernel": kernel_name if not coll
                          else kernel_name + " + search every ~27 ticks (time per tick, bytes of the step)",
@@ -558,7 +553,6 @@ def step_leg(args, R, n, workload, steps, warmup, traffic=(None, "not requested"
                 "algorithmic_bytes_per_uav_list_tick": cb,
                 "algorithmic_bytes_per_uav_search_tick": COLLISION_BYTES["search_tick_per_uav"] + COLLISION_BYTES["search_tick_per_candidate"] * kbar,
                 "search_candidates_per_uav": kbar, "search_bytes": search_bytes, "search_ms": search_ms,
-                "search_kernels": "k_pack_insert<1> + k_query2<1, 3> (collide.hip), 16 searches back to back between two hipEvents",
                 "search_achieved": search_bytes / (search_ms * 1e-3) / 1e9, "search_frac": search_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ticks_per_search": (int(ticks) / max(1, int(searches))),
                 "achieved_whole_tick": (b_alg + cb) * n / (kern_ms * 1e-3) / 1e9,
@@ -584,6 +578,15 @@ def sub_record(rec):
         out["cpu_baseline"] = dict(out["cpu_baseline"])
         for k in ("compiler_flags", "unit"):
             out["cpu_baseline"].pop(k, None)
+    return out
+
+
+def mini_record(rec):
+    """a sub-record cut down to what the line needs of the secondary workloads"""
+    out = sub_record(rec)
+    out.pop("unit", None), out.pop("regions", None), out.pop("value_device_time", None)
+    out["config"] = {k: out["config"][k] for k in ("workload", "uavs_per_gpu", "arith") if k in out["config"]}
+    out["roofline"] = {k: out["roofline"][k] for k in ("achieved", "frac", "kernel", "kernel_avg_ms") if k in out["roofline"]}
     return out
 
 
@@ -693,7 +696,7 @@ def io_tick_record(args, n=100_000, ticks=150, warm=20):
         el = (time.perf_counter() - t0) / ticks
         res[name] = {"ms_per_tick": el * 1e3, "value": n / el, "d2h_GBps": out_bytes / el / 1e9, "pcie_GBps_both_ways": (out_bytes + in_bytes) / el / 1e9}
     del sw
-    return {"workload": f"BASELINE configs[2] ({n} x500, actuator references) + per tick: staged command upload, full publisher payload download",
+    return {"workload": f"BASELINE configs[2] ({n} x500) + per tick: command block up, every UAV's publisher payload down",
             "unit": "UAV-steps/s", "ticks": ticks, "bytes_down_per_tick": out_bytes, "bytes_up_per_tick": in_bytes,
             "serial": res["serial"], "pipelined": res["pipelined"], "speedup": res["serial"]["ms_per_tick"] / res["pipelined"]["ms_per_tick"]}
 
@@ -880,12 +883,12 @@ def main():
         out["config4"] = sub_record(rec)
         # the bit-faithful flavour (reference operation order, no FMA contraction) on the headline workload
         rec, _, _ = step_leg(args, R, 100_000, "actuator", 300, 50, min_ms=30.0, arith="literal")
-        out["literal"] = sub_record(rec)
+        out["literal"] = mini_record(rec)
         # BASELINE configs[1]: 400 f550 hexarotors, position cascade, no collisions (launch-bound: one wave per seven SIMDs)
         rec, st2, cmd2 = step_leg(args, R, 400, "config2", 2000, 200, min_ms=30.0, airframe="f550")
         if R.rank == 0 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, st2, cmd2, workload="config2", uavs=400, airframe="f550", seconds=min(args.cpu_seconds, 4.0))
-        out["config2"] = sub_record(rec)
+        out["config2"] = mini_record(rec)
         # the same swarm with ten makeStep rounds per launch (mrs_swarm_step_n's substeps_per_launch: state kept in registers across the
         # rounds — legal while commands are constant and collisions are off, results identical); no roofline credit for the fusion
         rec, _, _ = step_leg(args, R, 400, "config2", 2000, 200, min_ms=30.0, airframe="f550", substeps=10)

@@ -552,7 +552,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
     if (i.copied) (void)hipEventDestroy(i.copied);
     if (i.unpacked) (void)hipEventDestroy(i.unpacked);
   }
-  if (s->stream_io) (void)hipStreamDestroy(s->stream_io);
+  for (hipStream_t st : {s->stream_io, s->stream_up})
+    if (st) (void)hipStreamDestroy(st);
   if (s->dT) (void)hipFree(s->dT);
   if (s->dBT) (void)hipFree(s->dBT);
   if (s->dMB) (void)hipFree(s->dMB);
@@ -713,7 +714,7 @@ int mrs_swarm_get_mixer_allocation(mrs_swarm_t* s, int32_t uav, double* out) {
 }
 
 int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, const double* payload, int32_t stride) {
-  MRS_ENTER(s);
+  MRS_ENTER_COMMANDS(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (mode < MRS_INPUT_UNKNOWN || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
@@ -740,7 +741,7 @@ int mrs_swarm_set_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mo
 }
 
 int mrs_swarm_set_feedforward(mrs_swarm_t* s, int32_t first, int32_t count, int32_t kind, const double* payload, int32_t stride) {
-  MRS_ENTER(s);
+  MRS_ENTER_COMMANDS(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (kind < 0 || kind > 3 || !payload || stride < 4) return fail(MRS_ERR_ARG, "bad feed-forward arguments");
@@ -1040,7 +1041,7 @@ int mrs_swarm_get_diag(mrs_swarm_t* s, mrs_diag_t* out) {
 }
 
 int mrs_swarm_timeout_input(mrs_swarm_t* s, int32_t first, int32_t count) {
-  MRS_ENTER(s);
+  MRS_ENTER_COMMANDS(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (count == 0) return MRS_OK;
@@ -1108,7 +1109,9 @@ int mrs_swarm_get_outputs_view(mrs_swarm_t* s, int32_t first, int32_t count, con
 }  // extern "C"
 namespace mrs_host {
 static int ensure_io_stream(mrs_swarm* s) {
-  if (!s->stream_io) HIPCHK(hipStreamCreateWithFlags(&s->stream_io, hipStreamNonBlocking));
+  if (s->stream_io) return MRS_OK;
+  HIPCHK(hipStreamCreateWithFlags(&s->stream_io, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&s->stream_up, hipStreamNonBlocking));
   return MRS_OK;
 }
 // pack behind everything queued on the step stream, copy on the copy stream (also called by drain() when the launch the pack
@@ -1237,7 +1240,7 @@ int mrs_swarm_input_staging(mrs_swarm_t* s, int32_t count, int32_t stride, doubl
 }
 
 int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t mode, int32_t stride) {
-  MRS_ENTER(s);
+  MRS_ENTER_COMMANDS(s);
   int rc = check_range(s, first, count);
   if (rc) return rc;
   if (mode < MRS_ACTUATOR_CMD || mode > MRS_POSITION_CMD) return fail(MRS_ERR_ARG, "bad input mode");
@@ -1255,9 +1258,9 @@ int mrs_swarm_commit_input(mrs_swarm_t* s, int32_t first, int32_t count, int32_t
   }
   HIPCHK(hipSetDevice(s->device));
   // the copy runs on the copy stream (beside whatever step is running), the step stream takes it in where this call stands
-  HIPCHK(hipStreamWaitEvent(s->stream_io, b.unpacked, 0));  // the unpack kernel of this block's previous commit
-  HIPCHK(hipMemcpyAsync(b.d, b.h, sizeof(double) * (size_t)count * (size_t)stride, hipMemcpyHostToDevice, s->stream_io));
-  HIPCHK(hipEventRecord(b.copied, s->stream_io));
+  HIPCHK(hipStreamWaitEvent(s->stream_up, b.unpacked, 0));  // the unpack kernel of this block's previous commit
+  HIPCHK(hipMemcpyAsync(b.d, b.h, sizeof(double) * (size_t)count * (size_t)stride, hipMemcpyHostToDevice, s->stream_up));
+  HIPCHK(hipEventRecord(b.copied, s->stream_up));
   HIPCHK(hipStreamWaitEvent(s->stream, b.copied, 0));
   HIPCHK(mrs_launch_unpack_rows(s->view(), b.d, stride, width, F_CMD, first, count, s->stream));
   HIPCHK(hipEventRecord(b.unpacked, s->stream));

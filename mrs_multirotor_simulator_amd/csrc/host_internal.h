@@ -80,6 +80,7 @@ extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
 extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st);
+extern "C" void      mrs_collide_heads_seq(const CollideWork* w, unsigned* expected, unsigned* seen);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
@@ -241,7 +242,9 @@ struct mrs_swarm {
     hipEvent_t        packed = nullptr, done = nullptr;
   };
   OutSlot     oslot[2];
-  hipStream_t stream_io = nullptr;  // copies of the pipelined download and of the staged command upload
+  // copy streams: download (stream_io) and command upload (stream_up) — one per direction, PCIe is full duplex.  (The download cut
+  // in two halves on two streams — two DMA engines — was measured and dropped: 0.40 against 0.38 ms per 13.6-MB tick.)
+  hipStream_t stream_io = nullptr, stream_up = nullptr;
   int32_t     out_tickets = 0;
   // staged command upload: two pinned row blocks + device copies, handed out in turn — the caller fills block k + 1 while the copy of
   // block k may still be in flight (`copied`: the host may refill the rows; `unpacked`: the device copy may be overwritten)
@@ -321,6 +324,7 @@ struct mrs_swarm {
 
 namespace mrs_host {
 int settle(mrs_swarm* s);
+int drain(mrs_swarm* s);
 }
 // entry of every call that reads or writes swarm state: collision ticks still pending on the device side are evaluated first
 #define MRS_ENTER(s)                                          \
@@ -330,6 +334,18 @@ int settle(mrs_swarm* s);
     if (_src) return _src;                                    \
   }
 
+
+// entry of a call that writes nothing but command / feed-forward columns and mode flags (setInput, setFeedforward, the input timeout):
+// the launches queued so far must have RUN — a replay after a stall would otherwise step with the new commands — but a collision tick
+// still pending stays pending: its evaluation reads positions only, and the next makeStep launch keeps the fused form.  (With
+// MRS_ENTER every command between two ticks cost a search pass of its own and two synchronisations.)
+#define MRS_ENTER_COMMANDS(s)                                                   \
+  MRS_LOCK(s);                                                                  \
+  if (s && !const_cast<mrs_swarm*>(s)->log.empty()) {                           \
+    if (hipSetDevice(s->device) != hipSuccess) return fail(MRS_ERR_HIP, "hipSetDevice"); \
+    int _src = mrs_host::drain(const_cast<mrs_swarm*>(s));                      \
+    if (_src) return _src;                                                      \
+  }
 
 namespace mrs_host {
 // ---- host_api.hip ----

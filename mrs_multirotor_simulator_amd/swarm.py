@@ -74,7 +74,7 @@ EXCHANGE_NONE, EXCHANGE_FULL_GATHER, EXCHANGE_EXPORT_SETS = 0, 1, 2
 COMP_WIDTHS = {1: (9, 9), 2: (18, 18), 3: (4, 8), 4: (3, 3), 5: (3, 3), 6: (4, 10), 7: (4, 5), 8: (10, 4), 9: (5, 4), 10: (4, 4)}
 
 
-EXCHANGE_NAMES = {0: "none", 1: "full all-gather of 48-B records per tick", 2: "export-set all-gather (boundary UAVs only), full gather on search ticks"}
+EXCHANGE_NAMES = {0: "none", 1: "full all-gather of 48-B records per tick", 2: "export-set all-gather (boundary UAVs), full gather on search ticks"}
 
 
 class Diag(C.Structure):
@@ -505,7 +505,7 @@ class Swarm:
         _check(_lib.mrs_swarm_comm_info(self._h, C.byref(ci)))
         d = {k: int(getattr(ci, k)) for k, _ in CommInfo._fields_}
         d["parallelism"] = (f"{d['world']} equal-count shards, {EXCHANGE_NAMES.get(d['exchange'], '?')}, "
-                            + ("RCCL" if d["rccl_ranks"] else "in-process / caller-supplied collective"))
+                            + ("RCCL" if d["rccl_ranks"] else "caller-supplied / in-process collective"))
         return d
 
     def comm_init_standin(self, world, rank, n_total, collective_latency_us, slab_width):
