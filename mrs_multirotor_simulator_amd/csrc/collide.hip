@@ -1097,8 +1097,7 @@ struct CollideWork {
   long long     exp_slot_cap = 0;
   // split sharded ticks: class of every 64-UAV block, list of the boundary blocks, epoch word per block (swarm_layout.h)
   uint32_t *    blk_class = nullptr, *blk_list = nullptr, *epoch = nullptr;
-  uint32_t*     host_heads = nullptr;  // pinned: heads of the slot maps + boundary-block count of the last search, word MRS_HEADS_SEQ = its stamp
-  uint32_t      heads_seq = 0;
+  uint32_t*     host_heads = nullptr;  // pinned: heads of the slot maps + boundary-block count of the last search
   long long     blk_cap = 0;
   Pos4*         x_send = nullptr;     // [1 + x_cap]: header + exported positions of this rank
   Pos4*         x_recv = nullptr;     // [world][1 + x_cap]
@@ -1809,7 +1808,7 @@ extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microsecond
 }
 
 namespace {
-__global__ void k_heads_to_host(const uint32_t* maps, long long stride, int world, const uint32_t* fctl, volatile uint32_t* host, uint32_t seq) {
+__global__ void k_heads_to_host(const uint32_t* maps, long long stride, int world, const uint32_t* fctl, volatile uint32_t* host) {
   const int q = threadIdx.x;
   if (q < world) {
     __hip_atomic_store(&host[2 * q], maps[(size_t)q * (size_t)stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1819,31 +1818,16 @@ __global__ void k_heads_to_host(const uint32_t* maps, long long stride, int worl
     __hip_atomic_store(&host[2 * world], fctl[CTL_NBND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&host[2 * world + 1], fctl[CTL_NL1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  // the stamp of this search, after every word above (one wave: its stores are drained first): the host spins on it instead of
-  // synchronising the stream — everything queued before this launch has completed when the stamp shows
-  __builtin_amdgcn_s_waitcnt(0);
-  __threadfence_system();
-  if (q == 0) __hip_atomic_store(&host[MRS_HEADS_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 // what the host needs of a search — every rank's export count and overflow counter, this rank's boundary-block count — in pinned host
-// memory after ONE small launch (two device-to-host copies cost a search 30 us), stamped last with the search's sequence number
-// (*seq_out; mrs_collide_heads_seq reads the stamp without synchronising)
+// memory after ONE small launch (two device-to-host copies cost a search 30 us); valid after the stream has been synchronised
 extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st) {
   if (!w || world > 64) return hipErrorInvalidValue;
-  if (!w->host_heads) {
-    CK(hipHostMalloc(&w->host_heads, sizeof(uint32_t) * 160, hipHostMallocMapped | hipHostMallocCoherent));
-    for (int k = 0; k < 160; k++) w->host_heads[k] = 0u;
-  }
-  w->heads_seq++;
-  hipLaunchKernelGGL(k_heads_to_host, dim3(1), dim3(64), 0, st, maps, stride, world, w->fctl, w->host_heads, w->heads_seq);
+  if (!w->host_heads) CK(hipHostMalloc(&w->host_heads, sizeof(uint32_t) * 160, hipHostMallocMapped | hipHostMallocCoherent));
+  hipLaunchKernelGGL(k_heads_to_host, dim3(1), dim3(64), 0, st, maps, stride, world, w->fctl, w->host_heads);
   *out = w->host_heads;
   return hipGetLastError();
-}
-// (expected stamp of the most recent search, the stamp the host sees right now)
-extern "C" void mrs_collide_heads_seq(const CollideWork* w, unsigned* expected, unsigned* seen) {
-  *expected = w ? w->heads_seq : 0u;
-  *seen     = (w && w->host_heads) ? ((const volatile uint32_t*)w->host_heads)[MRS_HEADS_SEQ] : 0u;
 }
 
 extern "C" const uint32_t* mrs_collide_host_heads(const CollideWork* w) { return w ? w->host_heads : nullptr; }

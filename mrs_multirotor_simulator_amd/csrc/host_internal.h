@@ -80,7 +80,6 @@ extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
 extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st);
-extern "C" void      mrs_collide_heads_seq(const CollideWork* w, unsigned* expected, unsigned* seen);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);

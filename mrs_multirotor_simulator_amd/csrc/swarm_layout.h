@@ -137,7 +137,6 @@ enum {
 // class of a 64-UAV block in a split sharded tick (set by every search from the neighbour lists)
 #define MRS_BLK_BOUNDARY 1u  // some UAV of the block lists a foreign UAV: the block is stepped by the boundary launch
 #define MRS_BLK_LAYER1   2u  // interior block, some UAV of it lists a UAV of a boundary block: waits for that block's epoch word
-#define MRS_HEADS_SEQ 159   // word of the pinned head block that holds the stamp of the search that wrote it (collide.hip k_heads_to_host)
 #define MRS_PRED_HORIZON 4u  // steps by which "may leave its skin" is announced ahead (why 4: DESIGN §5)
 // peer-window exchange (collide.hip k_peer_allgather): the windows of all ranks as this process addresses them
 #define MRS_MAX_PEERS 64
