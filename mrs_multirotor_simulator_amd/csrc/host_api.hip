@@ -540,6 +540,8 @@ int mrs_swarm_destroy(mrs_swarm_t* s) {
   if (s->dSt) (void)hipFree(s->dSt);
   if (s->hSt) (void)hipHostFree(s->hSt);
   if (s->hOut) (void)hipHostFree(s->hOut);
+  for (hipStream_t st : {s->stream_io, s->stream_up})
+    if (st) (void)hipStreamSynchronize(st);  // (a copy may still be in flight into / out of the pinned blocks freed below)
   for (auto& o : s->oslot) {
     if (o.d) (void)hipFree(o.d);
     if (o.h) (void)hipHostFree(o.h);
