@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies what tools/gpu_final.sh left under gpurun_out/final_<round>/ into profiles/<round>_* (run HERE, after the two gpurun calls)
-R=${1:-r04}; S=gpurun_out/final_$R; P=profiles
+R=${1:-r05}; S=gpurun_out/final_$R; P=profiles
 cp $S/bench_all.jsonl $P/${R}_bench_all.jsonl
 cp $S/gpu_tests.log $P/${R}_gpu_tests.log
 cp $S/sharded_rank_cost.log $P/${R}_sharded_rank_cost.log

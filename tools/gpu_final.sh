@@ -2,7 +2,7 @@
 # The one call behind profiles/<round>_*: pytest -m gpu, the bench lines, the rocprofv3 evidence (tools/profile_round.sh), the sharded
 # rank's cost and timeline, the facade loop, smoke().   usage (through gpurun, two calls of at most 20 minutes):
 #   bash tools/gpu_final.sh r04 tests      (suite + bench lines)        bash tools/gpu_final.sh r04 profiles      (everything else)
-R=${1:-r04}; PART=${2:-all}
+R=${1:-r05}; PART=${2:-all}
 set -x
 export TMPDIR=/tmp
 OUT=gpurun_out/final_$R
