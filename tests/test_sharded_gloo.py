@@ -1,10 +1,12 @@
-"""world_size-2 `gloo` tests (CPU) of the multi-GPU collision exchange — LAYOUT ONLY: shard ranges, the padded all-gather layout of
-the Python orchestrator (mrs_multirotor_simulator_amd/sharded.py) and that shard-local collision results equal the single-process
-result.  The local engine here is the CPU oracle (test infrastructure) behind the same three calls the GPU engine implements, so
-this file does NOT exercise mrs_swarm_tick_sharded_n.  The library's own protocol is covered elsewhere: its host decisions
-(csrc/sharded_protocol.h) on a multi-rank CPU model under random host skew in tests/test_sharded_protocol.py, the whole protocol in
-separate PROCESSES on the GPU box in tests/test_sharded_multiprocess_gpu.py / test_peer_window_gpu.py / test_sharded_chaos_gpu.py,
-and bench.py's N > 1 path end to end in tests/test_bench_rehearsal_gpu.py."""
+"""world_size-2/3 `gloo` tests (CPU) of the multi-GPU collision exchange.
+(1) LAYOUT: shard ranges, the padded all-gather layout of the Python orchestrator (mrs_multirotor_simulator_amd/sharded.py) and that
+shard-local collision results equal the single-process result — the local engine there is the CPU oracle (test infrastructure)
+behind the same three calls the GPU engine implements, so that part does not exercise mrs_swarm_tick_sharded_n.
+(2) PROTOCOL (round 5): the library's own host decisions (csrc/sharded_protocol.h, what export_ticks calls) driven from separate
+processes bound by gloo collectives that carry the stall / warning words — all ranks must issue the same launches under real
+asynchrony between hosts, with a negative control.  The device side of the protocol runs on the GPU box
+(tests/test_sharded_multiprocess_gpu.py, test_peer_window_gpu.py, test_sharded_chaos_gpu.py); bench.py's N > 1 path end to end in
+tests/test_bench_rehearsal_gpu.py."""
 import os
 import sys
 
@@ -220,3 +222,172 @@ def test_export_set_exchange_matches_single_process(tmp_path, oracle, world):
         assert int(d["ticks"]) == n_ticks and 2 <= int(d["searches"]) <= n_ticks // 4, (int(d["searches"]), n_ticks)
         assert int(d["cap"]) < len(own)
     assert covered.all()
+
+
+# ---- the library's own protocol decisions (csrc/sharded_protocol.h) across PROCESSES: every rank is a process with a host thread that
+# issues launches (at most `lead` ahead of its device, on mirror words it reads at arbitrary moments, under random sleeps) and a device
+# thread that runs them in order, each launch behind the gloo all-gather of the headers of the launch before — the role the export
+# collective plays on the GPUs.  Reports (warning W, stall T) are raised by scripted launches on scripted ranks.  Whatever the
+# interleaving: all ranks issue the SAME number of launches (else the collectives would not match up — here a gloo timeout, on
+# hardware a hang), no launch after T steps on any rank, all ranks agree on T, W and the ticks that ran.  The arithmetic of ONE process
+# with a random scheduler is tests/cpp/sharded_protocol_test.cpp; this is the same protocol with real asynchrony between hosts.
+def _protocol_shim():
+    import ctypes as C
+    import subprocess
+    so = os.path.join(ROOT, "tests", "cpp", "sharded_protocol_shim.so")
+    src = os.path.join(ROOT, "tests", "cpp", "sharded_protocol_shim.cpp")
+    hdr = os.path.join(ROOT, "mrs_multirotor_simulator_amd", "csrc", "sharded_protocol.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", src, "-o", so])
+    L = C.CDLL(so)
+    u = C.c_uint
+    L.sp_host_is_behind.argtypes, L.sp_host_is_behind.restype = [u, u, u, C.c_int], C.c_int
+    L.sp_search_ahead.argtypes, L.sp_search_ahead.restype = [u, C.c_int], u
+    L.sp_segment_last.argtypes, L.sp_segment_last.restype = [u, u, u, u, u], u
+    L.sp_ticks_ran.argtypes, L.sp_ticks_ran.restype = [u, u, u], u
+    L.sp_search_due.argtypes, L.sp_search_due.restype = [u, u, C.c_int], C.c_int
+    return L
+
+
+def _min_nz(a, b):
+    return b if a == 0 else (a if b == 0 else min(a, b))
+
+
+def _protocol_worker(rank, world, port, n_segments, out_dir):
+    import threading
+    import time
+    from datetime import timedelta
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    L = _protocol_shim()
+    script = np.random.default_rng(4242)           # the same scenario on every rank
+    skew = np.random.default_rng(1000 + rank)      # this host's own pace
+    results = []
+    for seg in range(n_segments):
+        lead = int(script.integers(1, 5))
+        split = bool(script.integers(0, 2))
+        vis = int(script.integers(3, 6)) if split else 1     # launches until a report is in every rank's words
+        horizon = 4 if split else 0                            # announced stall indices in the split protocol
+        n_ticks = int(script.integers(8, 40))
+        reports = [(int(script.integers(0, world)), int(script.integers(1, n_ticks + 1)), bool(script.integers(0, 3) == 0)) for _ in range(int(script.integers(0, 4)))]
+        ahead = L.sp_search_ahead(lead, int(split)) if not os.environ.get("MRS_TEST_BREAK_PROTOCOL") else 1  # (negative control: a search queued too soon after a warning)
+        st = {"issued": 0, "last": n_ticks, "done": False, "mirT": 0, "mirW": 0, "mirP": 0, "hdrT": 0, "hdrW": 0, "error": None}
+        gathered, ran = {}, {}
+        lock = threading.Condition()
+
+        def device():
+            k = 0
+            try:
+                while True:
+                    with lock:
+                        while st["issued"] <= k and not st["done"]:
+                            lock.wait(0.05)
+                        if st["issued"] <= k:
+                            return
+                    k += 1
+                    # launch k runs behind the collective of launch k - 1 (gathered[k - 1] exists: this thread made it)
+                    T, W = st["hdrT"], st["hdrW"]
+                    if k > vis:
+                        for q in range(world):
+                            T, W = _min_nz(T, gathered[k - vis][q][0]), _min_nz(W, gathered[k - vis][q][1])
+                    with lock:
+                        st["hdrT"], st["hdrW"] = T, W
+                        if T:
+                            st["mirT"] = T
+                        if W:
+                            st["mirW"] = W
+                        ran[k] = not (T != 0 and k > T)
+                        if ran[k]:
+                            st["mirP"] = k
+                        lock.notify_all()
+                    time.sleep(float(skew.uniform(0, 3e-4)))
+                    if ran[k]:
+                        for (r, launch, stall) in reports:
+                            if r == rank and launch == k:
+                                with lock:
+                                    if stall:
+                                        st["hdrT"] = _min_nz(st["hdrT"], k + horizon)
+                                        if horizon == 0:
+                                            st["mirT"] = _min_nz(st["mirT"], k + horizon)
+                                    else:
+                                        st["hdrW"] = _min_nz(st["hdrW"], k)
+                                    lock.notify_all()
+                    mine = torch.tensor([st["hdrT"], st["hdrW"]], dtype=torch.int64)
+                    everyone = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(everyone, mine)   # the export collective of tick k: carries every rank's header words
+                    gathered[k] = [(int(e[0]), int(e[1])) for e in everyone]
+            except Exception as e:  # noqa: BLE001 - a mismatched collective (ranks disagree on the launch count) ends here
+                st["error"] = f"{type(e).__name__}: {e}"
+
+        dev = threading.Thread(target=device)
+        dev.start()
+        while True:  # the host of export_ticks: wait_for_progress, segment_last, launch
+            nxt = st["issued"] + 1
+            if nxt > st["last"]:
+                break
+            with lock:
+                while L.sp_host_is_behind(nxt, st["mirP"], st["mirT"], lead) and st["error"] is None:
+                    lock.wait(0.02)
+                T, W = st["mirT"], st["mirW"]
+            if st["error"]:
+                break
+            time.sleep(float(skew.uniform(0, 4e-4)) if skew.integers(0, 3) == 0 else 0.0)  # (decides on what it read a moment ago)
+            st["last"] = L.sp_segment_last(st["last"], T, W, lead, ahead)
+            if nxt > st["last"]:
+                break
+            with lock:
+                st["issued"] = nxt
+                lock.notify_all()
+        with lock:
+            st["done"] = True
+            lock.notify_all()
+        dev.join(90)
+        assert not dev.is_alive() and st["error"] is None, (seg, st["error"])
+        # the final fold of the segment: every rank ends with the same words
+        mine = torch.tensor([st["hdrT"], st["hdrW"], st["issued"]], dtype=torch.int64)
+        everyone = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        T = W = 0
+        for e in everyone:
+            T, W = _min_nz(T, int(e[0])), _min_nz(W, int(e[1]))
+        issued = [int(e[2]) for e in everyone]
+        assert len(set(issued)) == 1, (seg, "ranks issued different numbers of launches", issued)
+        launched = issued[0]
+        for k in range(1, launched + 1):
+            assert ran[k] == (not (T != 0 and k > T)), (seg, rank, k, ran[k], T)
+        t_ran = L.sp_ticks_ran(T, 1, launched)
+        assert t_ran == (T if (T != 0 and T <= launched) else launched)
+        if W != 0 and T == 0:
+            assert launched == min(W + ahead - 1, n_ticks), (seg, W, ahead, launched)
+        if T != 0:
+            assert launched <= T + lead + 1, (seg, T, lead, launched)
+        results.append((launched, T, W, int(L.sp_search_due(T, W, int(launched < n_ticks)))))
+    np.save(os.path.join(out_dir, f"protocol_rank{rank}.npy"), np.array(results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_protocol_decisions_across_processes(tmp_path, world):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    n_segments = 40
+    mp.spawn(_protocol_worker, args=(world, port, n_segments, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"protocol_rank{r}.npy")) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(res[r], res[0])            # every rank: the same launches, words and decision in every segment
+    assert (res[0][:, 1] != 0).sum() >= 3 and (res[0][:, 2] != 0).sum() >= 3 and (res[0][:, 3] == 1).sum() >= 5  # stalls, warnings, searches happened
+
+
+def test_protocol_negative_control_is_caught(tmp_path, monkeypatch):
+    """the same model with a search queued ONE launch after a warning instead of lead + 3 / lead + 6: hosts that have not seen the
+    warning yet issue more launches than the others — the collectives stop matching up and the run fails (on hardware: a hang)"""
+    import socket
+    monkeypatch.setenv("MRS_TEST_BREAK_PROTOCOL", "1")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with pytest.raises(Exception):
+        mp.spawn(_protocol_worker, args=(2, port, 40, str(tmp_path)), nprocs=2, join=True)
