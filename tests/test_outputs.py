@@ -197,3 +197,85 @@ def test_pipelined_outputs_survive_a_stall_of_the_lazy_collision_ticks(mrs, orac
     fused, stalls, replayed, ahead = b.fused_stats()
     print(f"pipelined outputs with lazy collision ticks: {fused} fused launches, {stalls} stalls, {replayed} replayed launches, worst relative difference {worst:.2e}")
     assert fused >= calls and stalls >= 1 and replayed >= 1, (fused, stalls, replayed)  # the case the test is about has happened
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_pipelined_loops_equal_their_synchronous_twins(mrs, oracle, seed):
+    """Random interleavings of what a publisher loop does — ticks with collisions (1-3 per call), commands for random ranges (staged rows or
+    mrs_swarm_set_input: both only DRAIN the queued launches, a pending collision tick stays with the next fused launch), input timeouts,
+    forces from outside (these settle), pipelined downloads waited for at random later moments (up to two in flight) — on one swarm,
+    against a twin that does the same with synchronous calls only.  Fast UAVs make launches stall under the packs.  Every payload and
+    the final state must agree."""
+    import bench
+    rng = np.random.default_rng(100 + seed)
+    n = 6_000
+    st, cmd = bench.make_inputs(n, "position+collisions", seed=40 + seed, volume_per_uav=14.0)
+    st["v"][:6] = [0.0, 160.0, 0.0]
+
+    def make():
+        g = mrs.Swarm(n, arith=mrs.ARITH_FAST)
+        g.construct(0, n, mrs.model_params("x500", ground_enabled=True, ground_z=0.0))
+        g.set_state(0, n, st["x"], st["v"], st["R"], st["omega"], st["motor_rpm"])
+        g.set_input(0, n, mrs.POSITION_CMD, cmd)
+        return g
+
+    a, b = make(), make()
+    in_flight, checked, worst = [], 0, 0.0  # (ticket, expected payload)
+
+    def check(k):
+        nonlocal checked, worst
+        ticket, want = in_flight.pop(k)
+        got = b.outputs_wait(ticket)
+        for f in got.dtype.names:
+            worst = max(worst, helpers.rel_linf(got[f], want[f]))
+            helpers.assert_close(got[f], want[f], 1e-9, f"seed {seed}, download {checked}: {f}")
+        checked += 1
+
+    for it in range(70):
+        op = rng.integers(0, 10)
+        if op <= 3:  # ticks
+            k = int(rng.integers(1, 4))
+            a.tick_n(0.001, k, True, False, 100.0)
+            b.tick_n(0.001, k, True, False, 100.0)
+        elif op <= 5:  # commands for a range
+            first = int(rng.integers(0, n - 200))
+            count = int(rng.integers(1, 200))
+            goal = np.concatenate([st["x"][first:first + count] + rng.uniform(-5, 5, (count, 3)), rng.uniform(-3, 3, (count, 1))], axis=1)
+            a.set_input(first, count, mrs.POSITION_CMD, goal)
+            if rng.integers(0, 2):
+                rows = b.input_staging(count, 4)
+                rows[:] = goal
+                b.commit_input(first, count, mrs.POSITION_CMD, 4)
+            else:
+                b.set_input(first, count, mrs.POSITION_CMD, goal)
+        elif op == 6:  # a download, pipelined on b
+            if len(in_flight) == 2:
+                check(0)
+            want = a.get_outputs().copy()
+            in_flight.append((b.get_outputs_async(), want))
+        elif op == 7 and in_flight:
+            check(int(rng.integers(0, len(in_flight))) if len(in_flight) == 1 else 0)
+        elif op == 8:
+            first = int(rng.integers(0, n - 50))
+            if rng.integers(0, 2):
+                a.timeout_input(first, 50)
+                b.timeout_input(first, 50)
+            else:
+                f = rng.normal(0, 1.0, (50, 3))
+                a.apply_force(first, 50, f)
+                b.apply_force(first, 50, f)
+        else:
+            hold = bool(rng.integers(0, 2))
+            first = int(rng.integers(0, n - 30))
+            a.set_hold(first, 30, hold)
+            b.set_hold(first, 30, hold)
+    while in_flight:
+        check(0)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        helpers.assert_close(sb[k], sa[k], 1e-9, f"seed {seed}: final {k}")
+    helpers.assert_close(b.get_pid(), a.get_pid(), 1e-9, "final PID state")
+    fused, stalls, replayed, ahead = b.fused_stats()
+    print(f"seed {seed}: {checked} pipelined downloads checked (worst {worst:.1e}); pipelined swarm: {fused} fused launches, {stalls} stalls, {replayed} replayed")
+    assert checked >= 3 and fused >= 20
