@@ -84,7 +84,7 @@ NOTES = {
                           "back to back between two hipEvents) against SURVEY 8d's (92 + 24 k) B per UAV, k measured on the run's positions; "
                           "per-kernel times: profiles/r05_collision_tick_*",
     "sub_records": "hbm_streaming: the headline kernel on 4 M UAVs; config4: BASELINE configs[3] (100 000 UAVs, position references + "
-                   "collisions + ground) as mrs_swarm_tick_n runs it; literal: the bit-faithful flavour on the headline workload; config2: "
+                   "collisions + ground) as mrs_swarm_tick_n runs it, and (spawned_in_cell_order) the same swarm spawned in the order mrs_cell_order suggests; literal: the bit-faithful flavour on the headline workload; config2: "
                    "BASELINE configs[1] (400 f550 on the tmux grid); io_tick: config 3 with the publisher payload of every UAV downloaded and a "
                    "command block uploaded every tick (SURVEY 8f rank 2), serial and pipelined; sharded_rank_standin: one rank of 8 x 125 000 "
                    "alone on the GPU behind a fixed-latency stand-in collective (NOT a multi-GPU measurement); config5: BASELINE configs[4] "
@@ -233,11 +233,8 @@ def spatial_order(x, order, cell=2.25):
     c = np.floor((x - x.min(axis=0)) / cell).astype(np.int64)
     if order == "xcell":
         return np.lexsort((c[:, 2], c[:, 1], c[:, 0]))
-    key = np.zeros(len(x), dtype=np.int64)
-    for b in range(20):
-        for a in range(3):
-            key |= ((c[:, a] >> b) & 1) << (3 * b + a)
-    return np.argsort(key, kind="stable")
+    from mrs_multirotor_simulator_amd import cell_order  # the library's own helper for callers that choose their spawn order (mrs_cell_order)
+    return cell_order(x, cell)
 
 
 def make_inputs(n, workload, seed, volume_per_uav=64.0, n_motors=4, order="random"):
@@ -881,6 +878,13 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args, st4, cmd4, workload="position+collisions", uavs=100_000, seconds=min(args.cpu_seconds, 8.0))
         del st4, cmd4
         out["config4"] = sub_record(rec)
+        # the same swarm spawned in the order mrs_cell_order suggests (indices follow space: VERDICT r4 item 1's data point)
+        keep_order, args.order = args.order, "morton"
+        rec, _, _ = step_leg(args, R, 100_000, "position+collisions", 300, 100, min_ms=30.0)
+        args.order = keep_order
+        if rec is not None:
+            out["config4"]["spawned_in_cell_order"] = {"order": "morton (mrs_cell_order)", "ms_per_step": rec["ms_per_step"], "device_ms_per_step": rec["device_ms_per_step"],
+                                                       "search_ms": rec["roofline_collision"]["search_ms"]}
         # the bit-faithful flavour (reference operation order, no FMA contraction) on the headline workload
         rec, _, _ = step_leg(args, R, 100_000, "actuator", 300, 50, min_ms=30.0, arith="literal")
         out["literal"] = mini_record(rec)

@@ -670,6 +670,16 @@ public:
     mrs_throw_on_error(mrs_slab_partition(p.data(), (int64_t)pos.size(), world, order.data()));
     return order;
   }
+  // a spawn order that follows space, for callers free to choose which UAV gets which index (mrs_cell_order): order[k] = the caller's
+  // index of the UAV to spawn k-th
+  static std::vector<int64_t> cellOrder(const std::vector<Eigen::Vector3d>& pos, double cell = 0.0) {
+    std::vector<double> p(pos.size() * 3);
+    for (size_t k = 0; k < pos.size(); k++)
+      for (int j = 0; j < 3; j++) p[k * 3 + (size_t)j] = pos[k](j);
+    std::vector<int64_t> order(pos.size());
+    mrs_throw_on_error(mrs_cell_order(p.data(), (int64_t)pos.size(), cell, order.data()));
+    return order;
+  }
   void synchronize() { mrs_throw_on_error(mrs_swarm_synchronize(s_)); }
   // collision ticks so far, and how many of them had to repeat the neighbour search
   std::pair<int64_t, int64_t> collisionStats() {

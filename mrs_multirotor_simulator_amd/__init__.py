@@ -5,4 +5,4 @@ from .swarm import (ACCELERATION_HDG_CMD, ACCELERATION_HDG_RATE_CMD, ACTUATOR_CM
                     ATTITUDE_CMD, ATTITUDE_RATE_CMD, CONTROL_GROUP_CMD, FF_ACCELERATION_HDG, FF_ACCELERATION_HDG_RATE,
                     FF_VELOCITY_HDG, FF_VELOCITY_HDG_RATE, INPUT_UNKNOWN, MAX_MOTORS, POSITION_CMD, TILT_HDG_RATE_CMD,
                     VELOCITY_HDG_CMD, VELOCITY_HDG_RATE_CMD, EXCHANGE_EXPORT_SETS, EXCHANGE_FULL_GATHER, LoopbackGroup, ModelParams, MrsError, Swarm,
-                    default_params, load_library, slab_partition)
+                    default_params, load_library, slab_partition, cell_order)

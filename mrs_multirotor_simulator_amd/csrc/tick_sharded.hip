@@ -149,6 +149,38 @@ int mrs_slab_partition(const double* pos_xyz, int64_t n_total, int32_t world, in
   return MRS_OK;
 }
 
+// Morton order of the neighbour-list cells (non-finite positions last, ties by index)
+int mrs_cell_order(const double* pos_xyz, int64_t n_total, double cell, int64_t* order) {
+  if (!pos_xyz || !order || n_total < 0) return fail(MRS_ERR_ARG, "bad order arguments");
+  if (!(cell > 0)) cell = 2.25;
+  double lo[3] = {0, 0, 0};
+  bool   any   = false;
+  for (int64_t k = 0; k < n_total; k++) {
+    const double* p = pos_xyz + 3 * k;
+    if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+    for (int a = 0; a < 3; a++) lo[a] = any ? std::min(lo[a], p[a]) : p[a];
+    any = true;
+  }
+  std::vector<uint64_t> key((size_t)n_total);
+  for (int64_t k = 0; k < n_total; k++) {
+    const double* p = pos_xyz + 3 * k;
+    uint64_t      m = ~0ull;
+    if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) {
+      m = 0;
+      for (int a = 0; a < 3; a++) {
+        double c = std::floor((p[a] - lo[a]) / cell);
+        if (c > 2097151.0) c = 2097151.0;  // 21 bits per axis
+        const uint64_t ci = (uint64_t)c;
+        for (int b = 0; b < 21; b++) m |= ((ci >> b) & 1ull) << (3 * b + a);
+      }
+    }
+    key[(size_t)k] = m;
+  }
+  for (int64_t k = 0; k < n_total; k++) order[k] = k;
+  std::stable_sort(order, order + n_total, [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+  return MRS_OK;
+}
+
 }  // extern "C"
 
 // ---- sharded ticks ----

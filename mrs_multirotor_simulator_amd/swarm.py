@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
     "mrs_swarm_debug_search_ms", "mrs_swarm_debug_neighbour_lists", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
-    "mrs_swarm_get_outputs_async", "mrs_swarm_outputs_wait",
+    "mrs_swarm_get_outputs_async", "mrs_swarm_outputs_wait", "mrs_cell_order",
 ]
 
 STATE_DTYPE = np.dtype([("x", "f8", 3), ("v", "f8", 3), ("v_prev", "f8", 3), ("R", "f8", (3, 3)), ("omega", "f8", 3), ("motor_rpm", "f8", 8),
@@ -166,6 +166,15 @@ def slab_partition(pos, world):
     pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
     order = np.zeros(len(pos), dtype=np.int64)
     _check(_lib.mrs_slab_partition(_dp(pos), len(pos), int(world), order.ctypes.data_as(C.POINTER(C.c_int64))))
+    return order
+
+
+def cell_order(pos, cell=0.0):
+    """mrs_cell_order: a spawn order that follows space (Morton key of the neighbour-list cells); order[k] = caller's index spawned k-th"""
+    load_library()
+    pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+    order = np.zeros(len(pos), dtype=np.int64)
+    _check(_lib.mrs_cell_order(_dp(pos), len(pos), float(cell), order.ctypes.data_as(C.POINTER(C.c_int64))))
     return order
 
 
@@ -289,6 +298,7 @@ def load_library():
         "mrs_swarm_get_states": [vp, i32, i32, vp],
         "mrs_swarm_get_outputs_async": [vp, i32, i32, ip],
         "mrs_swarm_outputs_wait": [vp, i32, C.POINTER(vp), ip],
+        "mrs_cell_order": [dp, C.c_int64, f64, C.POINTER(C.c_int64)],
     }
     for name, args in sig.items():
         if os.environ.get("MRS_SWARM_LIB") and not hasattr(L, name):

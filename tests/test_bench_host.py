@@ -73,3 +73,26 @@ def test_guarded_peer_record_turns_a_failed_child_run_into_a_record():
     args = bench.parse()
     rec = bench.peer_leg_in_children(args)
     assert "error" in rec and rec.get("transport") == "peer", rec
+
+
+def test_cell_order_is_a_permutation_that_follows_space():
+    """mrs_cell_order (host only): a permutation; UAVs that follow each other in it are close in space; unusable positions go last"""
+    import numpy as np
+    import mrs_multirotor_simulator_amd as M
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 200, (20000, 3)) * [1, 1, 0.2]
+    x[123] = np.nan
+    o = M.cell_order(x)
+    assert sorted(o.tolist()) == list(range(len(x))) and o[-1] == 123
+    xs = x[o[:-1]]
+    step_sorted = np.linalg.norm(np.diff(xs, axis=0), axis=1)
+    step_random = np.linalg.norm(np.diff(x[:-1][x[:-1, 0] == x[:-1, 0]], axis=0), axis=1)
+    assert np.median(step_sorted) < 0.1 * np.median(step_random)
+    assert np.array_equal(M.cell_order(x, 2.25), o)  # (the default cell edge)
+
+
+def test_explain_prints_the_notes_without_a_gpu():
+    r = _run("--explain")
+    import json
+    notes = json.loads(r.stdout)
+    assert r.returncode == 0 and {"timing", "roofline", "roofline_collision", "sub_records", "rehearsal"} <= set(notes)
