@@ -918,7 +918,18 @@ def main():
                 if R.rehearsal:
                     out["rehearsal"] = "MRS_BENCH_REHEARSAL=1: every rank on cuda:0, gloo process group — code path only, NOT a multi-GPU measurement"
                     out["n_devices"] = 1
-                print(json.dumps(compact_line(out)), flush=True)
+                line = compact_line(out)
+                dropped = []
+                # the driver keeps the last 8 KB of stdout: should the line ever outgrow that, the least important records go first
+                # (and the line says which) rather than the head of the line being cut off
+                for k in ("first_region_wall_ms_per_step", "literal", "config2", "sharded_rank_standin", "io_tick", "cpu_baseline"):
+                    if len(json.dumps(line)) <= 7900:
+                        break
+                    if k in line:
+                        del line[k]
+                        dropped.append(k)
+                        line["dropped_for_size"] = dropped
+                print(json.dumps(line), flush=True)
             return True
 
     if args.config5 == "on" or (args.config5 == "auto" and not args.pmc_child and args.workload == "actuator"):
