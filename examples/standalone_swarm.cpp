@@ -34,15 +34,26 @@ int main(int argc, char** argv) {
       sim.inputReceived(i);
     }
     std::printf("%d UAVs, simulation_rate %.0f Hz, realtime_factor %.2f\n", (int)uavs.size(), sim.config().simulation_rate, sim.config().realtime_factor);
+    // the publishers of the reference (odometry / IMU / range of every UAV after every step, src/uav_system_ros.cpp:278-282; the pose
+    // array every tick, src/multirotor_simulator.cpp:215): one packed payload per tick, downloaded while the next tick runs
+    long long published = 0;
+    double    uav0[3]   = {0, 0, 0}, stamp = 0.0;
+    sim.setPublisher([&](double t, const void* payload, int count) {
+      const mrs_uav_output_t* out = static_cast<const mrs_uav_output_t*>(payload);
+      if (count > 0)
+        for (int j = 0; j < 3; j++) uav0[j] = out[0].position[j];
+      stamp = t;
+      published++;
+    });
     double elapsed = 0.0;
     while (elapsed < wall_seconds) {
       const double chunk = std::min(1.0, wall_seconds - elapsed);
       sim.spinFor(chunk);
       elapsed += chunk;
-      const mrs_uav_output_t* out = swarm.getOutputsView(0, 1);
-      const auto              cs  = swarm.collisionStats();
-      std::printf("t_sim %8.3f s  rtf %.2f  uav0 at (%.2f, %.2f, %.2f)  collision ticks %lld (searches %lld)\n", sim.simTime(), sim.actualRtf(),
-                  out->position[0], out->position[1], out->position[2], (long long)cs.first, (long long)cs.second);
+      sim.flushPublisher();  // (the payload of the last tick: nothing stays in flight while this thread prints)
+      const auto cs = swarm.collisionStats();
+      std::printf("t_sim %8.3f s  rtf %.2f  uav0 at (%.2f, %.2f, %.2f)  ticks %lld, collision ticks %lld (searches %lld)  published %lld payloads, last stamped %.3f s\n",
+                  sim.simTime(), sim.actualRtf(), uav0[0], uav0[1], uav0[2], (long long)sim.ticks(), (long long)cs.first, (long long)cs.second, published, stamp);
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -141,3 +141,7 @@ def test_standalone_example_runs(mrs):
     assert len(lines) == 2 and "3 UAVs" in out.stdout
     z = float(lines[-1].split("(")[1].split(")")[0].split(",")[2])
     assert z > 0.6, out.stdout  # spawned at 0.5 m, goal 5 m higher
+    # the pipelined publisher: one payload per tick, the last one stamped with the loop's sim time
+    ticks = int(lines[-1].split(" ticks ")[1].split(",")[0])
+    published = int(lines[-1].split("published")[1].split()[0])
+    assert published == ticks and abs(float(lines[-1].split("last stamped")[1].split()[0]) - float(lines[-1].split()[1])) < 1e-9, lines[-1]
