@@ -1203,11 +1203,19 @@ int mrs_swarm_get_states(mrs_swarm_t* s, int32_t first, int32_t count, mrs_uav_s
     s->hSt = nullptr;
     s->st_cap = 0;
     HIPCHK(hipMalloc(&s->dSt, sizeof(mrs_uav_state_t) * (size_t)count));
-    HIPCHK(hipHostMalloc(&s->hSt, sizeof(mrs_uav_state_t) * (size_t)count, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&s->hSt, sizeof(mrs_uav_state_t) * (size_t)count, hipHostMallocMapped));
     s->st_cap = count;
   }
-  HIPCHK(mrs_launch_pack_states(s->view(), first, count, s->dSt, s->stream));
-  HIPCHK(hipMemcpyAsync(s->hSt, s->dSt, sizeof(mrs_uav_state_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  // few UAVs (the facade's lone object, a pool's round): the pack kernel stores straight into the pinned block — no copy command
+  // behind it (a DMA of a few hundred bytes costs the stream ~8 us, a third of a single object's makeStep + getState)
+  static const int direct_max = getenv("MRS_DIRECT_STATE_MAX") ? atoi(getenv("MRS_DIRECT_STATE_MAX")) : 1024;
+  mrs_uav_state_t* host_dev = nullptr;
+  if (count <= direct_max && hipHostGetDevicePointer((void**)&host_dev, s->hSt, 0) == hipSuccess && host_dev) {
+    HIPCHK(mrs_launch_pack_states(s->view(), first, count, host_dev, s->stream));
+  } else {
+    HIPCHK(mrs_launch_pack_states(s->view(), first, count, s->dSt, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hSt, s->dSt, sizeof(mrs_uav_state_t) * (size_t)count, hipMemcpyDeviceToHost, s->stream));
+  }
   HIPCHK(hipStreamSynchronize(s->stream));
   memcpy(out, s->hSt, sizeof(mrs_uav_state_t) * (size_t)count);
   return MRS_OK;
