@@ -639,10 +639,18 @@ def sharded_rank_record(args):
     """sub-record of the default line: what one rank of an 8-rank config-5 run costs per tick at 10 and 20 us of collective latency
     (split form, and the serial form at 10 us) — the figures DESIGN §5 and BASELINE.md quote, reproducible from the driver's own run"""
     runs = [sharded_rank_cost(latency_us=10.0, ticks=400), sharded_rank_cost(latency_us=20.0, ticks=400), sharded_rank_cost(latency_us=10.0, ticks=400, split=False)]
+    # the same with the collectives' BYTES charged as well (the stand-in's fixed latency makes the 42 MB of a search tick's record gather
+    # as cheap as an ordinary tick's 54 KB): (world - 1) blocks received at 300 GB/s, a ring all-gather's bus bandwidth over xGMI
+    os.environ["MRS_STANDIN_GBPS"] = "300"
+    try:
+        wire = sharded_rank_cost(latency_us=10.0, ticks=400)
+    finally:
+        os.environ.pop("MRS_STANDIN_GBPS", None)
     keep = ("split_ticks", "boundary_blocks", "blocks", "export_set", "searches", "replayed_noop_ticks")
     return {"workload": "rank 4 of 8 x 125000 UAVs of BASELINE configs[4] alone on the GPU, fixed-latency stand-in collective: NOT a multi-GPU measurement",
             "unit": "us per tick (wall clock, 400 ticks incl. searches)",
             "split_10us": runs[0]["us_per_tick"], "split_20us": runs[1]["us_per_tick"], "serial_10us": runs[2]["us_per_tick"],
+            "split_10us_plus_bytes_at_300GBps": wire["us_per_tick"],
             "split_run": {k: runs[0][k] for k in keep}, "serial_run": {k: runs[2][k] for k in keep}}
 
 

@@ -295,6 +295,12 @@ int mrs_swarm_comm_init_loopback(mrs_swarm_t* s, mrs_loopback_group_t* g, int32_
 int mrs_loopback_group_set_rendezvous(mrs_loopback_group_t* g, int32_t on);
 int mrs_swarm_debug_chaos(mrs_swarm_t* s, int32_t max_sleep_us, uint64_t seed);
 int mrs_swarm_get_split_stats(mrs_swarm_t* s, int64_t* split_ticks, int64_t* boundary_blocks);
+/* Neighbour searches of the export-set exchange on this rank: all of them; the ones that ran on a HALO exchange — each rank sends the
+ * records that lie inside another rank's box of the last search (plus the distance a UAV may have moved), 64 B each, instead of
+ * gathering all 48-B records (MRS_SEARCH_HALO=0 switches that off); the halo searches that had to be repeated on all records (a UAV
+ * further from its rank's old hull than the margin, or more entries than the block held); the entries per rank the next one sends.
+ * Results do not depend on which exchange a search used. */
+int mrs_swarm_get_search_stats(mrs_swarm_t* s, int64_t* searches, int64_t* halo_searches, int64_t* halo_repeats, int64_t* halo_capacity);
 /* test / measurement hook: a kernel that keeps `stream` (a hipStream_t of this process) busy for `microseconds` — stands in for the
  * latency of a collective in tools/sharded_rank_cost.py */
 int mrs_debug_stream_delay(void* stream, double microseconds);

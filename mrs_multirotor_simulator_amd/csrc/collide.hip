@@ -1082,6 +1082,13 @@ struct CollideWork {
   PosRecord* g_rec_build = nullptr;  // gathered mode: all records as of this rank's last rebuild
   long long  g_cap = 0;
   bool       g_lists_live = false;
+  // halo exchange of a search tick (mrs_collide_halo_*): instead of every rank's ALL records, the records that can be within the list
+  // radius of another rank's UAVs travel — [header | entries] of 64 B, the header's `j` = count, `pad` = flags
+  HaloEntry* h_send = nullptr;   // [1 + h_cap]
+  HaloEntry* h_recv = nullptr;   // [world][1 + h_cap]
+  long long  h_cap = 0, h_alloc = 0;  // entries per block in use; entries allocated (all blocks together, headers included)
+  int        h_world = 0;
+  uint32_t*  h_ctl = nullptr;    // [0] entries appended, [1] flags (MRS_HALO_*)
   bool       g_export_form = false;  // the last gathered search was one of the export-set exchange: lists end up in slot form, and of
                                      // the record copy only this rank's own range (the skin references) is kept
   // fused step + collision evaluation (step_device.inc *_coll): double-buffered positions, control words, pinned host mirror
@@ -1111,6 +1118,8 @@ static void free_work(CollideWork* w) {
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
   (void)hipFree(w->g_bbox);
   w->g_bbox = nullptr;
+  (void)hipFree(w->h_send); (void)hipFree(w->h_ctl);  // (h_recv lives in h_send's allocation)
+  w->h_send = w->h_recv = nullptr; w->h_ctl = nullptr; w->h_cap = w->h_alloc = 0;
   (void)hipFree(w->exp_slot); (void)hipFree(w->x_send);  // (x_recv and x_const live in x_send's allocation)
   w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
   w->exp_slot_cap = w->x_cap = 0;
@@ -1369,6 +1378,181 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   w->g_lists_live  = true;
   w->g_export_form = export_form;
   w->lists_live    = false;  // the local-mode skin hook of the step kernel is off
+  return hipGetLastError();
+}
+
+// ---- halo exchange of a search tick (sharded swarms, export-set exchange) ----
+// A search needs, on every rank, the records of all UAVs within the list radius of one of its own.  The full exchange gathers
+// EVERYTHING (48 B x n_total per rank: 42 MB received at 8 x 125 000) and lets every rank scan it.  With spatially coherent shards
+// almost none of it matters: rank q can only list a record that lies in q's bounding box widened by the list radius.  Every rank knows
+// every rank's box of the LAST search (it travels at the tail of the slot-map blocks).  Rank q's new box lies inside its old one grown
+// by `margin` as long as none of q's UAVs is more than `margin` outside the hull of their old positions — q CHECKS exactly that on its
+// own records (MRS_HALO_MOVED otherwise: a search is due when somebody has moved SKIN2/2, so a margin of SKIN2 is rarely left; a host
+// write can).  So a rank sends the records inside some other rank's old box grown by `margin`, tagged with their local index; receivers write them into the
+// SAME table the full gather would have filled (record of UAV j of rank q at q x n_max + j — lists, export marks and translation
+// keep their global indices) and insert them, and their own records, into the hash.  Any rank's flag (moved, more entries than the
+// block holds) makes every rank repeat the search with the full exchange (tick_sharded.hip).
+#define MRS_HALO_MOVED    1u  // an own record lies outside this rank's box of the last search widened by the motion margin
+#define MRS_HALO_OVERFLOW 2u  // more entries than the block holds
+namespace {
+__device__ __forceinline__ const double* halo_box(const uint32_t* maps, long long stride, int boxw, int q) {
+  return reinterpret_cast<const double*>(maps + (size_t)q * (size_t)stride + (size_t)boxw);
+}
+// own records -> own part of the table; the ones some other rank may list -> the send block
+__global__ void __launch_bounds__(256) k_halo_select(const PosRecord* own, int n, PosRecord* table_own, const uint32_t* maps, long long stride, int boxw, int world,
+                                                     int rank, double margin, double own_margin, HaloEntry* send, unsigned hcap, uint32_t* hctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PosRecord r = own[i];
+  table_own[i]      = r;
+  if (!record_usable(r)) return;
+  bool wanted = false;
+  for (int q = 0; q < world; q++) {
+    const double* b  = halo_box(maps, stride, boxw, q);  // the box of q's last search: hull of its records then, widened by the list radius
+    const double  m  = q == rank ? own_margin : margin;  // (own_margin = margin - that widening: this record within `margin` of the old hull)
+    const bool    in = r.x >= b[0] - m && r.y >= b[1] - m && r.z >= b[2] - m && r.x <= b[3] + m && r.y <= b[4] + m && r.z <= b[5] + m;
+    if (q == rank) {
+      if (!in) atomicOr(&hctl[1], MRS_HALO_MOVED);  // (also when this rank had no usable record then: NaN bounds compare false)
+    } else if (in) {
+      wanted = true;
+    }
+  }
+  if (!wanted) return;
+  const uint32_t k = atomicAdd(&hctl[0], 1u);
+  if (k >= hcap) {
+    atomicOr(&hctl[1], MRS_HALO_OVERFLOW);
+    return;
+  }
+  HaloEntry e;
+  e.x = r.x; e.y = r.y; e.z = r.z; e.mass = r.mass; e.arm_length = r.arm_length; e.prop_radius = r.prop_radius;
+  e.j = (unsigned long long)i;
+  e.pad = 0ull;
+  send[1u + k] = e;
+}
+__global__ void k_halo_header(HaloEntry* send, uint32_t* hctl, unsigned force_flags) {
+  HaloEntry h;
+  h.x = h.y = h.z = h.mass = h.arm_length = h.prop_radius = 0.0;
+  h.j   = hctl[0];  // (the number WANTED: more than the block holds with MRS_HALO_OVERFLOW — the capacity the repeat needs)
+  h.pad = hctl[1] | force_flags;
+  send[0] = h;
+  hctl[0] = hctl[1] = 0u;  // (ready for the next search)
+}
+// own records and the received entries into the hash (the insert of k_insert_gathered_lists without the scan of n_total records)
+__global__ void __launch_bounds__(256) k_halo_insert(SwarmDev sw, PosRecord* table, PosRecord* rec_build, const HaloEntry* recv, int world, int rank, unsigned hcap,
+                                                     long long n_max, uint32_t mask, uint2* head, uint2* next, uint32_t* ctl, int table_id, uint2* head_to_clear,
+                                                     uint32_t table_size, const double* bb, int ib) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    ctl[4 + table_id] = 1u;
+    ctl[2] += 1u;
+  }
+  if (ctl[4 + (table_id ^ 1)]) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = (uint32_t)t; u < table_size; u += stride) head_to_clear[u] = make_uint2(0u, 0u);
+  }
+  long long g;
+  PosRecord r;
+  if (t < sw.n) {
+    g            = (long long)rank * n_max + t;
+    r            = table[g];
+    rec_build[g] = r;  // the reference of the skin tests (own range only, as in the export form of the full exchange)
+  } else {
+    const long long e = t - sw.n;
+    const int       q = (int)(e / hcap);
+    const unsigned  k = (unsigned)(e - (long long)q * hcap);
+    if (q >= world || q == rank) return;
+    const HaloEntry* blk = recv + (size_t)q * (size_t)(1u + hcap);
+    if ((unsigned long long)k >= blk[0].j) return;  // (k < hcap: an overflowing block is read as far as it goes, the search is repeated anyway)
+    const HaloEntry en = blk[1u + k];
+    if (en.j >= (unsigned long long)n_max) return;  // (never: a block that is not one of ours)
+    g = (long long)q * n_max + (long long)en.j;
+    r.x = en.x; r.y = en.y; r.z = en.z; r.mass = en.mass; r.arm_length = en.arm_length; r.prop_radius = en.prop_radius;
+    table[g] = r;
+  }
+  uint32_t qc;
+  Cell     c = cell_q<2>(r.x, r.y, r.z, qc);
+  c.ok = c.ok && r.x >= bb[0] && r.y >= bb[1] && r.z >= bb[2] && r.x <= bb[3] && r.y <= bb[4] && r.z <= bb[5];
+  insert_uav2(g, c, qc, mask, ib, head, next);
+}
+// this rank's widened box of THIS search at the tail of its slot-map block: what the next search's selection on the other ranks uses
+__global__ void k_halo_box_out(uint32_t* map, int boxw, const double* bb) {
+  double* o = reinterpret_cast<double*>(map + boxw);
+  if (threadIdx.x < 6) o[threadIdx.x] = bb[threadIdx.x];  // (no usable own record: +-1e300 +- the widening — nothing is inside, as it should be)
+}
+}  // namespace
+
+extern "C" hipError_t mrs_collide_halo_prepare(CollideWork** work, int world, long long cap, hipStream_t st) {
+  if (!*work) *work = new CollideWork();
+  CollideWork* w = *work;
+  if (cap < 1 || world < 1) return hipErrorInvalidValue;
+  const long long need = (cap + 1) * (long long)(1 + world);
+  if (need > w->h_alloc) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->h_send);
+    w->h_send = nullptr;
+    w->h_alloc = 0;
+    const long long alloc = need + need / 4;
+    CK(hipMalloc(&w->h_send, sizeof(HaloEntry) * (size_t)alloc));
+    CK(hipMemsetAsync(w->h_send, 0, sizeof(HaloEntry) * (size_t)alloc, st));
+    w->h_alloc = alloc;
+  }
+  w->h_recv  = w->h_send + (cap + 1);  // (a collective writes every block whole: what another capacity left behind is overwritten)
+  w->h_cap   = cap;
+  w->h_world = world;
+  if (!w->h_ctl) {
+    CK(hipMalloc(&w->h_ctl, sizeof(uint32_t) * 4));
+    CK(hipMemsetAsync(w->h_ctl, 0, sizeof(uint32_t) * 4, st));
+  }
+  return hipSuccess;
+}
+extern "C" long long mrs_collide_halo_capacity(const CollideWork* w) { return w ? w->h_cap : 0; }
+extern "C" void*     mrs_collide_halo_send(const CollideWork* w) { return w ? (void*)w->h_send : nullptr; }
+extern "C" void*     mrs_collide_halo_recv(const CollideWork* w) { return w ? (void*)w->h_recv : nullptr; }
+
+// own records (packed into `own`) -> the table's own part + the send block; `maps` = every rank's slot-map block of the LAST search
+// (its tail holds that rank's widened box), `margin` = how far a UAV may be from where it was then
+// not_ready: this rank cannot search on a halo (its tables are not the ones a full search of the export-set exchange left) — its header says so
+extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, const PosRecord* own, PosRecord* table, long long n_max, int rank, int world,
+                                              const uint32_t* maps, long long stride, int boxw, int not_ready, hipStream_t st) {
+  if (!w || !w->h_send) return hipErrorInvalidValue;
+  const double margin = SKIN2, widening = SQRT3_UP + SKIN2 + 1e-6;  // (the widening of k_own_bbox_final)
+  if (sw.n > 0)
+    hipLaunchKernelGGL(k_halo_select, dim3((unsigned)((sw.n + 255) / 256)), dim3(256), 0, st, own, sw.n, table + (size_t)rank * (size_t)n_max, maps, stride, boxw, world,
+                       rank, margin, margin - widening - 1e-9, w->h_send, (unsigned)w->h_cap, w->h_ctl);
+  hipLaunchKernelGGL(k_halo_header, dim3(1), dim3(1), 0, st, w->h_send, w->h_ctl, not_ready ? MRS_HALO_MOVED : 0u);
+  return hipGetLastError();
+}
+extern "C" int mrs_collide_halo_ready(const CollideWork* w, long long n_total) {
+  return w && w->nbr && w->g_rec_build && n_total <= w->g_cap && w->g_lists_live && w->g_export_form && w->g_bbox ? 1 : 0;
+}
+
+// the search itself on the table the halo exchange has filled: own box, insert (own records + received entries), list-building query
+extern "C" hipError_t mrs_collide_run_lists_halo(SwarmDev sw, CollideWork** work, PosRecord* table, long long n_total, long long n_max, int rank, int world,
+                                                 int crash, double rebounce, hipStream_t st) {
+  if (!*work) return hipErrorInvalidValue;
+  CollideWork* w = *work;
+  if (!w->h_recv || !mrs_collide_halo_ready(w, n_total)) return hipErrorInvalidValue;  // (a full search came first)
+  crash = mode_word(sw, crash);
+  CK(ensure_tables(w, n_total, st));
+  const uint32_t T = w->cap_T, mask = T - 1;
+  const int      tid = w->cur;
+  w->cur ^= 1;
+  const int       ib = index_bits(n_total);
+  const long long my_offset = (long long)rank * n_max;
+  hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, table, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, 1);
+  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, 1);
+  const long long threads = (long long)sw.n + (long long)world * w->h_cap;
+  hipLaunchKernelGGL(k_halo_insert, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sw, table, w->g_rec_build, w->h_recv, world, rank, (unsigned)w->h_cap, n_max,
+                     mask, w->head[tid], w->next, w->ctl, tid, w->head[tid ^ 1], T, w->g_bbox, ib);
+  launch_query2<2>(query_lpu(sw.n), sw, table, n_total, my_offset, mask, ib, w->head[tid], w->next, crash, rebounce, w->ctl, w->fcur, 1, w->nbr, w->nbr_cnt, nullptr,
+                   nullptr, 0u, st);
+  w->fcur ^= 1;
+  return hipGetLastError();
+}
+// this rank's box of the search just done -> tail of its slot-map block (after mrs_collide_export_mark, which wipes the block)
+extern "C" hipError_t mrs_collide_halo_box_out(CollideWork* w, uint32_t* map_send, int boxw, hipStream_t st) {
+  if (!w || !w->g_bbox) return hipSuccess;  // (never searched: the tail keeps the NaN words of the map's reset)
+  hipLaunchKernelGGL(k_halo_box_out, dim3(1), dim3(64), 0, st, map_send, boxw, w->g_bbox);
   return hipGetLastError();
 }
 
@@ -1669,9 +1853,11 @@ __global__ void k_stream_delay(long long ticks) {
 namespace {
 // The collective of the measurement stand-in as ONE kernel that lasts `ticks` of the 100 MHz clock (one wave watches it — a real
 // collective keeps a few waves busy, not the chip): the rank's own block of `bytes` bytes is copied to the places
-// of ranks rank-1, rank, rank+1 of `recv`; when the blocks are 48-byte records (`records`), absent ranks read as NaN records and the
-// two images are moved one slab width to either side.
-__global__ void k_standin_gather(const uint4* send, uint4* recv, long long vec_per_rank, int rank, int world, int records, double width, long long ticks) {
+// of ranks rank-1, rank, rank+1 of `recv`; when the blocks are 48-byte records (`kind` 1), absent ranks read as NaN records and the
+// two images are moved one slab width to either side.  Likewise the 64-byte entries of a halo exchange (kind 2; absent ranks: an
+// empty header) and the search box at the tail of a slot map (kind 3, `aux` = its first 16-byte vector; absent ranks: NaN bounds).
+__global__ void k_standin_gather(const uint4* send, uint4* recv, long long vec_per_rank, int rank, int world, int kind, long long aux, double width,
+                                 long long ticks) {
   const long long t_start = wall_clock64();
   const long long total = vec_per_rank * (long long)world;
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long long)gridDim.x * blockDim.x) {
@@ -1679,15 +1865,25 @@ __global__ void k_standin_gather(const uint4* send, uint4* recv, long long vec_p
     const long long j = v - (long long)q * vec_per_rank;
     const int       d = q - rank;
     if (d < -1 || d > 1) {
-      if (records) recv[v] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (kind == 1 || (kind == 3 && j >= aux && j < aux + 3)) recv[v] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (kind == 2 && j < 4) recv[v] = make_uint4(0u, 0u, 0u, 0u);
       continue;
     }
     uint4 x = send[j];
-    if (records && d != 0 && j % 3 == 0) {  // a 48-byte record = three 16-byte vectors; the first holds x and y
+    // a 48-byte record = three 16-byte vectors, a halo entry four, the first holds x and y; a box = xmin ymin | zmin xmax | ymax zmax
+    const bool lo = d != 0 && ((kind == 1 && j % 3 == 0) || (kind == 2 && j % 4 == 0) || (kind == 3 && j == aux));
+    const bool hi = d != 0 && kind == 3 && j == aux + 1;
+    if (lo) {
       double px = __builtin_bit_cast(double, make_uint2(x.x, x.y));
       px += (double)d * width;
       const uint2 b = __builtin_bit_cast(uint2, px);
       x.x = b.x; x.y = b.y;
+    }
+    if (hi) {
+      double px = __builtin_bit_cast(double, make_uint2(x.z, x.w));
+      px += (double)d * width;
+      const uint2 b = __builtin_bit_cast(uint2, px);
+      x.z = b.x; x.w = b.y;
     }
     recv[v] = x;
   }
@@ -1697,14 +1893,14 @@ __global__ void k_standin_gather(const uint4* send, uint4* recv, long long vec_p
   }
 }
 }  // namespace
-extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int records, double width,
-                                                hipStream_t st) {
+extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int kind, long long aux,
+                                                double width, hipStream_t st) {
   if (bytes % 16 != 0) return hipErrorInvalidValue;
   const long long vec = (long long)(bytes / 16);
   long long       blocks = (vec * world + 255) / 256;
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_standin_gather, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)send, (uint4*)recv, vec, rank, world, records, width,
+  hipLaunchKernelGGL(k_standin_gather, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)send, (uint4*)recv, vec, rank, world, kind, aux, width,
                      (long long)(latency_us * 100.0));
   return hipGetLastError();
 }
@@ -1808,8 +2004,26 @@ extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microsecond
 }
 
 namespace {
-__global__ void k_heads_to_host(const uint32_t* maps, long long stride, int world, const uint32_t* fctl, volatile uint32_t* host) {
+__global__ void k_heads_to_host(const uint32_t* maps, long long stride, int world, const uint32_t* fctl, volatile uint32_t* host, const HaloEntry* halo,
+                                unsigned hcap) {
   const int q = threadIdx.x;
+  {  // the halo headers of a search that ran on a halo exchange: the largest number of entries any rank wanted to send, all flags
+    unsigned long long cnt = 0ull, fl = 0ull;
+    if (halo && q < world) {
+      const HaloEntry h = halo[(size_t)q * (size_t)(1u + hcap)];
+      cnt = h.j > 0xFFFFFFFFull ? 0xFFFFFFFFull : h.j;
+      fl  = h.pad;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long c2 = __shfl_xor(cnt, o), f2 = __shfl_xor(fl, o);
+      cnt = c2 > cnt ? c2 : cnt;
+      fl |= f2;
+    }
+    if (q == 0) {
+      __hip_atomic_store(&host[2 * world + 2], (uint32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host[2 * world + 3], (uint32_t)fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (q < world) {
     __hip_atomic_store(&host[2 * q], maps[(size_t)q * (size_t)stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&host[2 * q + 1], maps[(size_t)q * (size_t)stride + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1822,10 +2036,11 @@ __global__ void k_heads_to_host(const uint32_t* maps, long long stride, int worl
 }  // namespace
 // what the host needs of a search — every rank's export count and overflow counter, this rank's boundary-block count — in pinned host
 // memory after ONE small launch (two device-to-host copies cost a search 30 us); valid after the stream has been synchronised
-extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st) {
+// halo != 0: the search ran on a halo exchange; words [2 world + 2] = most entries wanted by a rank, [2 world + 3] = the flags of all ranks
+extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, int halo, const uint32_t** out, hipStream_t st) {
   if (!w || world > 64) return hipErrorInvalidValue;
   if (!w->host_heads) CK(hipHostMalloc(&w->host_heads, sizeof(uint32_t) * 160, hipHostMallocMapped | hipHostMallocCoherent));
-  hipLaunchKernelGGL(k_heads_to_host, dim3(1), dim3(64), 0, st, maps, stride, world, w->fctl, w->host_heads);
+  hipLaunchKernelGGL(k_heads_to_host, dim3(1), dim3(64), 0, st, maps, stride, world, w->fctl, w->host_heads, halo ? w->h_recv : nullptr, (unsigned)w->h_cap);
   *out = w->host_heads;
   return hipGetLastError();
 }

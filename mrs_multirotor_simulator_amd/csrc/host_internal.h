@@ -79,7 +79,18 @@ extern "C" hipError_t mrs_launch_step_coll_fast(SwarmDev sw, CollDev cd, double 
 extern "C" void       mrs_collide_export_part(CollDev* cd, int part, unsigned n_bnd, double dt, int announce);
 extern "C" hipError_t mrs_collide_handoff_init(CollideWork* w, int n, unsigned tau, hipStream_t st);
 extern "C" const uint32_t* mrs_collide_ctl_words(const CollideWork* w);
-extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, const uint32_t** out, hipStream_t st);
+extern "C" hipError_t mrs_collide_heads_to_host(CollideWork* w, const uint32_t* maps, long long stride, int world, int halo, const uint32_t** out, hipStream_t st);
+// halo exchange of a search tick (collide.hip)
+extern "C" hipError_t mrs_collide_halo_prepare(CollideWork** work, int world, long long cap, hipStream_t st);
+extern "C" long long  mrs_collide_halo_capacity(const CollideWork* w);
+extern "C" void*      mrs_collide_halo_send(const CollideWork* w);
+extern "C" void*      mrs_collide_halo_recv(const CollideWork* w);
+extern "C" int        mrs_collide_halo_ready(const CollideWork* w, long long n_total);
+extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, const PosRecord* own, PosRecord* table, long long n_max, int rank, int world,
+                                              const uint32_t* maps, long long stride, int boxw, int not_ready, hipStream_t st);
+extern "C" hipError_t mrs_collide_run_lists_halo(SwarmDev sw, CollideWork** work, PosRecord* table, long long n_total, long long n_max, int rank, int world,
+                                                 int crash, double rebounce, hipStream_t st);
+extern "C" hipError_t mrs_collide_halo_box_out(CollideWork* w, uint32_t* map_send, int boxw, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);
@@ -94,7 +105,7 @@ extern "C" hipError_t mrs_launch_pack_states(SwarmDev sw, int first, int count, 
 extern "C" hipError_t mrs_launch_peer_allgather(const MrsPeerWindows* pw, const void* send, void* recv, size_t bytes, int rank, int world, unsigned seq,
                                                 size_t slot_bytes, unsigned* tickets, unsigned ticket_total, unsigned* err_host, unsigned* bpp_out,
                                                 hipStream_t st);
-extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int records, double width,
+extern "C" hipError_t mrs_launch_standin_gather(const void* send, void* recv, size_t bytes, int rank, int world, double latency_us, int kind, long long aux, double width,
                                                 hipStream_t st);
 extern "C" hipError_t mrs_launch_stream_delay(hipStream_t st, double microseconds);
 
@@ -173,7 +184,7 @@ struct mrs_swarm {
   // measurement stand-in (mrs_swarm_comm_init_standin): ONE rank of `world` alone on the device; its neighbours in the slab order
   // are images of itself one slab width away, and every collective costs a fixed latency
   bool   comm_standin = false;
-  double standin_delay_us = 0.0, standin_width = 0.0;
+  double standin_delay_us = 0.0, standin_width = 0.0, standin_gbps = 0.0;  // gbps > 0: bytes of a collective / that rate on top of the latency
   // peer-window exchange (mrs_swarm_peer_window_create / mrs_swarm_comm_init_peer; collide.hip k_peer_allgather): ranks write their
   // blocks straight into each other's device memory, one kernel per collective on the swarm's stream, no collective library
   bool               comm_peer = false;
@@ -197,6 +208,11 @@ struct mrs_swarm {
   int64_t   x_searches = 0, x_ticks = 0, x_noop_ticks = 0;
   // split sharded ticks: between two searches the blocks that hold a boundary UAV are stepped by a small launch on
   // `stream`, followed there by the collective, while the interior launch runs on `stream2` and never waits for a collective
+  // halo exchange of a search (collide.hip mrs_collide_halo_*; MRS_SEARCH_HALO=0: every search gathers all records, as up to round 4)
+  bool      halo_trace = false;  // MRS_HALO_TRACE=1: one line on stderr per halo search
+  bool      halo_enabled = true, halo_ok = false, halo_pass = false;  // ok: the last search left every rank's box in the maps; pass: the queued search is a halo one
+  int64_t   halo_cap = 0, halo_backoff = 0;                                            // entries per block of the next halo search — the same on every rank
+  int64_t   x_halo_searches = 0, x_halo_repeats = 0;
   bool      early_search = true;    // tuning: MRS_EARLY_SEARCH=0 — a certain search waits for the segment's synchronisation (round 3)
   bool      shard_split = true;     // tuning: MRS_SHARD_SPLIT=0 keeps every tick in the serial form (fused launch, then the collective)
   int       split_min_blocks = 512; // tuning / tests: MRS_SHARD_SPLIT_MIN_BLOCKS
@@ -385,6 +401,12 @@ int  comm_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes);
 int  comm_setup(mrs_swarm* s, int world, int rank, int64_t n_total);
 int  comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total);
 // words of one rank's slot map in the collective of a search: [export count, overflow count, n_max slots], padded to whole 16-byte units
-inline int64_t map_stride(const mrs_swarm* s) { return (s->comm_n_max + 2 + 3) & ~(int64_t)3; }
+// a rank's slot-map block: [count | overflow lanes | slot of UAV 0 .. n_max-1 | pad to 16 B | box of this search: 6 doubles]
+inline int64_t map_boxw(const mrs_swarm* s) { return (s->comm_n_max + 2 + 3) & ~(int64_t)3; }
+inline int64_t map_stride(const mrs_swarm* s) { return map_boxw(s) + 12; }
+// a halo block never exceeds the block of a full gather (the peer windows are sized by that): 64 B x (1 + cap) <= 48 B x n_max
+inline int64_t halo_cap_max(const mrs_swarm* s) { return (int64_t)(sizeof(PosRecord) * (size_t)s->comm_n_max / sizeof(HaloEntry)) - 1; }
+// will the next search of the export-set exchange run on a halo exchange?  (the same answer on every rank: all of it follows from collective calls)
+inline bool halo_next(const mrs_swarm* s) { return s->halo_enabled && s->halo_ok && s->comm_world > 1 && s->halo_backoff == 0 && s->halo_cap >= 1 && s->halo_cap <= halo_cap_max(s); }
 }  // namespace mrs_host
 using namespace mrs_host;

@@ -107,6 +107,11 @@ struct Pos4 {
 #define MRS_HDR_STALL 0
 #define MRS_HDR_WARN  1
 #define MRS_HDR_ERROR 2  // the rank's CTL_ERROR bits: every rank's call fails when any rank's kernels reported an error
+// one record of the halo exchange of a search tick (collide.hip mrs_collide_halo_*): a PosRecord + the UAV's index on its rank
+struct HaloEntry {
+  double             x, y, z, mass, arm_length, prop_radius;
+  unsigned long long j, pad;  // (header entry of a block: j = entries that follow, pad = flags)
+};
 struct PartnerConst {
   double mass, arm_length, prop_radius, _pad;
 };

@@ -36,6 +36,11 @@ int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   s->comm_n_max   = (n_total + world - 1) / world;
   if (s->comm_n_max < 1) s->comm_n_max = 1;
   s->x_ok         = false;
+  s->halo_ok      = false;
+  s->halo_cap     = 0;
+  s->halo_backoff = 0;
+  if (const char* e = getenv("MRS_SEARCH_HALO")) s->halo_enabled = atoi(e) != 0;
+  s->halo_trace = getenv("MRS_HALO_TRACE") && atoi(getenv("MRS_HALO_TRACE")) != 0;
   s->x_last_overflow.assign((size_t)world, 0u);
   if (const char* e = getenv("MRS_EXCHANGE")) s->exchange = atoi(e) == 1 ? MRS_EXCHANGE_FULL_GATHER : MRS_EXCHANGE_EXPORT_SETS;
   HIPCHK(hipMalloc(&s->comm_send, sizeof(PosRecord) * (size_t)s->comm_n_max));
@@ -58,6 +63,16 @@ int mrs_swarm_get_split_stats(mrs_swarm_t* s, int64_t* split_ticks, int64_t* bou
   return MRS_OK;
 }
 
+int mrs_swarm_get_search_stats(mrs_swarm_t* s, int64_t* searches, int64_t* halo_searches, int64_t* halo_repeats, int64_t* halo_capacity) {
+  MRS_LOCK(s);
+  if (!s) return fail(MRS_ERR_ARG, "null swarm");
+  if (searches) *searches = s->x_searches;
+  if (halo_searches) *halo_searches = s->x_halo_searches;
+  if (halo_repeats) *halo_repeats = s->x_halo_repeats;
+  if (halo_capacity) *halo_capacity = halo_next(s) ? s->halo_cap : 0;
+  return MRS_OK;
+}
+
 int mrs_swarm_debug_chaos(mrs_swarm_t* s, int32_t max_sleep_us, uint64_t seed) {
   MRS_LOCK(s);
   if (!s || max_sleep_us < 0) return fail(MRS_ERR_ARG, "bad chaos arguments");
@@ -72,6 +87,7 @@ int mrs_swarm_set_exchange(mrs_swarm_t* s, int32_t exchange) {
   if (!s || (exchange != MRS_EXCHANGE_FULL_GATHER && exchange != MRS_EXCHANGE_EXPORT_SETS)) return fail(MRS_ERR_ARG, "bad exchange");
   if (exchange != s->exchange) {
     s->x_ok = false;
+    s->halo_ok = false;
     mrs_collide_invalidate_gathered(s->cwork);  // the two exchanges keep their neighbour lists in different forms
   }
   s->exchange = exchange;
@@ -97,6 +113,7 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   peer_release(s);
   s->comm_world = 0;
   s->x_ok       = false;
+  s->halo_ok    = false;
   mrs_collide_invalidate_gathered(s->cwork);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
@@ -121,7 +138,8 @@ int mrs_swarm_comm_info(mrs_swarm_t* s, mrs_comm_info_t* out) {
     out->export_capacity   = mrs_collide_export_capacity(s->cwork);
     out->export_count      = s->x_export_count;
     out->bytes_per_tick    = (int64_t)sizeof(Pos4) * (1 + out->export_capacity);
-    out->bytes_per_rebuild = full + (int64_t)sizeof(uint32_t) * map_stride(s);
+    // (a search on a halo exchange sends the entries its neighbours can list instead of all records)
+    out->bytes_per_rebuild = (halo_next(s) ? (int64_t)sizeof(HaloEntry) * (1 + s->halo_cap) : full) + (int64_t)sizeof(uint32_t) * map_stride(s);
   } else {
     out->bytes_per_tick = out->bytes_per_rebuild = full;
   }
@@ -192,6 +210,7 @@ int full_gather_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Col
   const int64_t n_rec = s->comm_n_max * s->comm_world;
   int           rc;
   s->x_ok    = false;
+  s->halo_ok = false;  // (the record table is about to hold other ticks' records; the next search of the export-set exchange is a full one)
   s->p_valid = false;
   s->fk_ok   = false;
   for (int k = 0; k < n_ticks; k++) {
@@ -217,38 +236,72 @@ int full_gather_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Col
 // first half: everything up to the point where the host needs numbers of its own — ENQUEUED only (no host wait), so that a search
 // that is certain can follow the last launches of a segment in stream order and the segment's one synchronisation serves both
 // dt: the step of the ticks that follow (the search also runs the displacement bound over MRS_PRED_HORIZON of them, split protocol only)
-int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c, double dt) {
+// The exchange of the search is a HALO exchange (collide.hip mrs_collide_halo_*) when the last search left every rank's box in the slot
+// maps: each rank sends the records some other rank can list, not all of them.  Whether that was enough is known with the head words
+// (every rank reads the same halo headers): export_search_finish repeats the search on the full exchange if not (allow_halo = false).
+int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, bool allow_halo) {
   const int     world = s->comm_world, rank = s->comm_rank;
   const int64_t n_max = s->comm_n_max, n_rec = n_max * world, stride = map_stride(s);
   int           rc;
   s->x_ok = false;
   s->x_searches++;
+  s->halo_pass = allow_halo && halo_next(s);
   if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
-  if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)n_max))) return rc;
   s->fext_active = true;
   s->nbr_dirty   = true;  // (a later single-GPU tick starts from a search of its own)
-  if (s->n > 0)
-    HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
+  if (s->halo_pass) {
+    s->x_halo_searches++;
+    HIPCHK(mrs_collide_halo_prepare(&s->cwork, world, s->halo_cap, s->stream));
+    // (a rank whose tables are not what a search of this exchange left — ticks of another kind in between, on this rank only — says so in its header)
+    const int ready = s->n == 0 || mrs_collide_halo_ready(s->cwork, n_rec);
+    HIPCHK(mrs_collide_halo_select(s->view(), s->cwork, s->comm_send, s->comm_recv, n_max, rank, world, s->x_map_recv, stride, (int)map_boxw(s), ready ? 0 : 1, s->stream));
+    if ((rc = comm_allgather(s, mrs_collide_halo_send(s->cwork), mrs_collide_halo_recv(s->cwork), sizeof(HaloEntry) * (size_t)(s->halo_cap + 1)))) return rc;
+    if (s->n > 0 && ready) HIPCHK(mrs_collide_run_lists_halo(s->view(), &s->cwork, s->comm_recv, n_rec, n_max, rank, world, c.crash, c.rebounce, s->stream));
+  } else {
+    if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)n_max))) return rc;
+    if (s->n > 0)
+      HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
+  }
   const long long cap = mrs_collide_export_capacity(s->cwork);
   HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, /*zero=*/0, s->stream));  // (zeroed by the marking launches)
   HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, stride, rank, s->x_map_send, s->shard_split ? (double)MRS_PRED_HORIZON * dt : -1.0, c.rebounce,
                                  s->stream));
+  HIPCHK(mrs_collide_halo_box_out(s->cwork, s->x_map_send, (int)map_boxw(s), s->stream));  // this search's box: what the next one's halo is chosen by
   if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
   // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
   const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch; valid once the stream has been synchronised)
-  HIPCHK(mrs_collide_heads_to_host(s->cwork, s->x_map_recv, stride, world, &heads, s->stream));
+  HIPCHK(mrs_collide_heads_to_host(s->cwork, s->x_map_recv, stride, world, s->halo_pass ? 1 : 0, &heads, s->stream));
   return MRS_OK;
 }
 
 // second half, behind a synchronisation of the stream: capacities, then the lists go into export form
 // may_leave: some UAV of some rank may leave its skin within MRS_PRED_HORIZON steps of the state the search ran on (or the bound was
 // not evaluated): the ticks that follow take the serial form until the launches' own announcements cover the horizon
-int export_search_finish(mrs_swarm* s, int* incomplete, bool* may_leave) {
+int export_search_finish(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, int* incomplete, bool* may_leave) {
   const int       world = s->comm_world, rank = s->comm_rank;
   const int64_t   n_max = s->comm_n_max;
   const uint32_t* heads = mrs_collide_host_heads(s->cwork);
   *incomplete = 0;
   if (!heads) return fail(MRS_ERR_HIP, "export-set search: no head words");
+  if (s->halo_pass) {
+    // the halo headers, the same on every rank: did every rank's halo hold what it had to (nobody outside the margin, nothing cut off)?
+    const uint32_t wanted = heads[2 * world + 2], flags = heads[2 * world + 3];
+    s->halo_pass = false;
+    const int64_t cap_max = halo_cap_max(s);
+    int64_t       next    = (((int64_t)wanted + (int64_t)wanted / 4 + 64 + 63) / 64) * 64;  // headroom: the sets drift from search to search
+    if (next > cap_max) next = cap_max;
+    if ((int64_t)wanted > cap_max) s->halo_backoff = 16;  // most records would travel anyway: the next searches gather them all
+    if (s->halo_trace)
+      fprintf(stderr, "[mrs halo] rank %d search %lld: most entries wanted by a rank %u, block capacity %lld (next %lld, at most %lld), flags %u%s\n", rank,
+              (long long)s->x_searches, wanted, (long long)s->halo_cap, (long long)next, (long long)cap_max, flags, flags ? " -> repeated on all records" : "");
+    s->halo_cap = next;
+    if (flags) {  // the lists of this pass may miss partners: the same search again, on all records (forces are set, not added; crashes only grow)
+      s->x_halo_repeats++;
+      int rc = export_search_enqueue(s, c, dt, /*allow_halo=*/false);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(s->stream));
+    }
+  }
   mrs_collide_host_words_reset(s->cwork);  // launch indices restart at 1: the host mirrors of the old segment's words are void
   const long long cap = mrs_collide_export_capacity(s->cwork);
   s->x_nbnd = s->n > 0 ? heads[2 * world] : 0u;
@@ -273,15 +326,21 @@ int export_search_finish(mrs_swarm* s, int* incomplete, bool* may_leave) {
   HIPCHK(mrs_collide_export_translate(s->view(), s->cwork, n_max, map_stride(s), rank, s->x_map_recv, s->comm_recv, s->stream));
   // (the lists are in export form now; collide.hip remembers that, and the full exchange would start with a search of its own)
   s->x_ok = true;
+  s->halo_ok = true;  // (every rank's box of this search sits in x_map_recv)
+  if (s->halo_cap < 1) {  // first guess, an eighth of a shard; the first halo search reports what is needed
+    s->halo_cap = ((n_max / 8 + 64 + 63) / 64) * 64;
+    if (s->halo_cap > halo_cap_max(s)) s->halo_cap = halo_cap_max(s);
+  }
+  if (s->halo_backoff > 0) s->halo_backoff--;
   s->tau  = 0;
   return MRS_OK;
 }
 
 int export_search(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, int* incomplete, bool* may_leave) {
-  int rc = export_search_enqueue(s, c, dt);
+  int rc = export_search_enqueue(s, c, dt, true);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(s->stream));  // (a stamp in pinned memory polled by the host instead: measured, 35.1-35.5 against 35.2 us per tick — no gain, removed)
-  return export_search_finish(s, incomplete, may_leave);
+  return export_search_finish(s, c, dt, incomplete, may_leave);
 }
 
 int launch_fused_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval) {
@@ -471,7 +530,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
     // turned into no-ops, which is the state the search belongs on either way.
     const unsigned launched = s->tau + 1 - first;
     const bool     early_search = s->early_search && mrs_protocol::search_due(stall_word(hw), warn_word(hw), done + (int)launched < n_ticks);
-    if (early_search && (rc = export_search_enqueue(s, c, dt))) return rc;
+    if (early_search && (rc = export_search_enqueue(s, c, dt, true))) return rc;
     HIPCHK(hipStreamSynchronize(s->stream));
     const unsigned T = stall_word(hw), W = warn_word(hw);  // identical on every rank
     const unsigned ran = mrs_protocol::ticks_ran(T, first, launched);
@@ -486,7 +545,7 @@ int export_ticks(mrs_swarm* s, double dt, int n_ticks, const mrs_swarm::Collide&
       int  incomplete = 0;
       bool may_leave  = true;
       if (early_search) {
-        if ((rc = export_search_finish(s, &incomplete, &may_leave))) return rc;
+        if ((rc = export_search_finish(s, c, dt, &incomplete, &may_leave))) return rc;
       } else if ((rc = export_search(s, c, dt, &incomplete, &may_leave))) {
         return rc;
       }

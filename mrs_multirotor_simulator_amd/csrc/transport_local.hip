@@ -117,7 +117,9 @@ int loopback_allgather(mrs_loopback_group* g, int rank, const void* send, void* 
 // this rank, so the export sets mirror each other as they do between real neighbours (positions of foreign partners are the
 // images' only at a search; between searches they read as far away — fine for a time measurement, meaningless as a simulation).
 int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) {
-  const bool records = bytes == sizeof(PosRecord) * (size_t)s->comm_n_max;
+  // what travels is told by where it comes from: position records, halo entries of a search, slot maps (with the search box at the tail)
+  const int       kind = send == (const void*)s->comm_send ? 1 : (s->cwork && send == mrs_collide_halo_send(s->cwork) ? 2 : (send == (const void*)s->x_map_send ? 3 : 0));
+  const long long aux  = kind == 3 ? (long long)(map_boxw(s) / 4) : 0;
   if (bytes % 16 != 0) {  // (a block that is no whole number of 16-byte units — none of the library's own collectives any more) plain copies
     HIPCHK(hipMemsetAsync(recv, 0, bytes * (size_t)s->comm_world, s->cstream));
     for (int d = -1; d <= 1; d++)
@@ -125,7 +127,11 @@ int standin_allgather(mrs_swarm* s, const void* send, void* recv, size_t bytes) 
         HIPCHK(hipMemcpyAsync((char*)recv + (size_t)(s->comm_rank + d) * bytes, send, bytes, hipMemcpyDeviceToDevice, s->cstream));
     return MRS_OK;
   }
-  HIPCHK(mrs_launch_standin_gather(send, recv, bytes, s->comm_rank, s->comm_world, s->standin_delay_us, records ? 1 : 0, s->standin_width, s->cstream));
+  // MRS_STANDIN_GBPS (default 0: off): the collective also takes the time its bytes need on the links — (world - 1) blocks received
+  // at that many GB/s — on top of the fixed latency; without it the 42 MB of a search tick's record gather cost as much as 54 KB
+  const double gbps    = s->standin_gbps;  // (read when the stand-in communicator is bound)
+  const double wire_us = gbps > 0.0 ? (double)bytes * (double)(s->comm_world - 1) / (gbps * 1e3) : 0.0;
+  HIPCHK(mrs_launch_standin_gather(send, recv, bytes, s->comm_rank, s->comm_world, s->standin_delay_us + wire_us, kind, aux, s->standin_width, s->cstream));
   return MRS_OK;
 }
 }  // namespace mrs_host
@@ -152,6 +158,7 @@ int mrs_swarm_comm_init_standin(mrs_swarm_t* s, int32_t world, int32_t rank, int
   s->comm_standin     = true;
   s->standin_delay_us = collective_latency_us;
   s->standin_width    = slab_width;
+  s->standin_gbps     = getenv("MRS_STANDIN_GBPS") ? atof(getenv("MRS_STANDIN_GBPS")) : 0.0;
   return comm_buffers(s, world, rank, n_total);
 }
 

@@ -46,7 +46,7 @@ int mrs_swarm_peer_window_create(mrs_swarm_t* s, int32_t world, int32_t rank, in
   // the largest block any collective of the sharded tick sends: the full gather of a search (one record per UAV of the largest shard)
   const int64_t n_max = (n_total + world - 1) / world > 0 ? (n_total + world - 1) / world : 1;
   size_t slot = sizeof(PosRecord) * (size_t)n_max;
-  if (slot < sizeof(uint32_t) * (size_t)(n_max + 8)) slot = sizeof(uint32_t) * (size_t)(n_max + 8);  // (the slot maps: n_max + 2 words, padded to 16-byte units)
+  if (slot < sizeof(uint32_t) * (size_t)(n_max + 20)) slot = sizeof(uint32_t) * (size_t)(n_max + 20);  // (the slot maps: n_max + 2 words padded to 16-byte units + the search box, map_stride)
   // (an export block is header + capacity records of 32 B, the capacity up to 1.5 x the largest export set + 127: export_search)
   if (slot < sizeof(Pos4) * ((size_t)n_max + (size_t)n_max / 2 + 129)) slot = sizeof(Pos4) * ((size_t)n_max + (size_t)n_max / 2 + 129);
   slot = (slot + 255) / 256 * 256;

@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "mrs_debug_pid_sequences", "mrs_swarm_debug_collision_words", "mrs_rccl_unique_id", "mrs_swarm_comm_init", "mrs_swarm_tick_sharded_n", "mrs_swarm_comm_destroy", "mrs_swarm_comm_info",
     "mrs_swarm_comm_init_custom", "mrs_loopback_group_create", "mrs_loopback_group_destroy", "mrs_swarm_comm_init_loopback", "mrs_swarm_set_exchange",
     "mrs_slab_partition", "mrs_swarm_get_fused_stats", "mrs_swarm_debug_component", "mrs_debug_pid_update", "mrs_swarm_set_state_pos", "mrs_swarm_set_pid", "mrs_swarm_clone",
-    "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
+    "mrs_loopback_group_set_rendezvous", "mrs_swarm_debug_chaos", "mrs_swarm_get_split_stats", "mrs_swarm_get_search_stats", "mrs_debug_stream_delay", "mrs_swarm_comm_init_standin",
     "mrs_swarm_peer_window_create", "mrs_swarm_comm_init_peer",
     "mrs_swarm_set_hold", "mrs_swarm_get_collision_stats", "mrs_swarm_get_outputs_view", "mrs_swarm_input_staging", "mrs_swarm_commit_input", "mrs_swarm_last_step_kernel_ms", "mrs_swarm_set_profiling",
     "mrs_swarm_debug_search_ms", "mrs_swarm_debug_neighbour_lists", "mrs_swarm_clone_resized", "mrs_swarm_copy_uavs", "mrs_swarm_step_range", "mrs_swarm_get_states",
@@ -271,6 +271,7 @@ def load_library():
         "mrs_loopback_group_set_rendezvous": [vp, i32],
         "mrs_swarm_debug_chaos": [vp, i32, C.c_uint64],
         "mrs_swarm_get_split_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+        "mrs_swarm_get_search_stats": [vp] + [C.POINTER(C.c_int64)] * 4,
         "mrs_debug_stream_delay": [vp, C.c_double],
         "mrs_swarm_comm_init_standin": [vp, i32, i32, C.c_int64, C.c_double, C.c_double],
         "mrs_swarm_peer_window_create": [vp, i32, i32, C.c_int64, C.POINTER(C.c_void_p), C.c_char_p],
@@ -547,6 +548,12 @@ class Swarm:
         a, b = C.c_int64(), C.c_int64()
         _check(_lib.mrs_swarm_get_split_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def search_stats(self):
+        """(searches, of them on a halo exchange, halo searches repeated on all records, entries per rank of the next halo block)"""
+        v = [C.c_int64() for _ in range(4)]
+        _check(_lib.mrs_swarm_get_search_stats(self._h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
 
     def comm_init_loopback(self, group, rank, n_total):
         _check(_lib.mrs_swarm_comm_init_loopback(self._h, group._h, int(rank), int(n_total)))
