@@ -626,10 +626,13 @@ def sharded_rank_cost(n_per_rank=125_000, world=8, ticks=600, latency_us=20.0, s
     el = time.perf_counter() - t0
     ci = g.comm_info()
     s1, nbnd = g.split_stats()
+    _, on_halo, repeats, halo_cap = g.search_stats()
     out = {"us_per_tick": el / ticks * 1e6, "ticks": ticks, "rank": rank, "world": world, "uavs_per_rank": hi - lo, "collective_latency_us": latency_us,
            "form": "split" if split else "serial", "split_ticks": int(s1 - s0), "boundary_blocks": int(nbnd), "blocks": (hi - lo + 63) // 64,
            "export_set": int(ci["export_count"]), "export_capacity": int(ci["export_capacity"]), "searches": int(ci["searches"] - c0["searches"]),
-           "replayed_noop_ticks": int(ci["noop_ticks"] - c0["noop_ticks"])}
+           "replayed_noop_ticks": int(ci["noop_ticks"] - c0["noop_ticks"]),
+           # (since the communicator was bound) searches on a halo exchange / repeated on all records; bytes a rank sends per tick and per search tick
+           "halo_searches": int(on_halo), "halo_repeats": int(repeats), "bytes_per_tick": int(ci["bytes_per_tick"]), "bytes_per_search_tick": int(ci["bytes_per_rebuild"])}
     g.comm_destroy()
     del g
     return out
@@ -639,14 +642,15 @@ def sharded_rank_record(args):
     """sub-record of the default line: what one rank of an 8-rank config-5 run costs per tick at 10 and 20 us of collective latency
     (split form, and the serial form at 10 us) — the figures DESIGN §5 and BASELINE.md quote, reproducible from the driver's own run"""
     runs = [sharded_rank_cost(latency_us=10.0, ticks=400), sharded_rank_cost(latency_us=20.0, ticks=400), sharded_rank_cost(latency_us=10.0, ticks=400, split=False)]
-    # the same with the collectives' BYTES charged as well (the stand-in's fixed latency makes the 42 MB of a search tick's record gather
-    # as cheap as an ordinary tick's 54 KB): (world - 1) blocks received at 300 GB/s, a ring all-gather's bus bandwidth over xGMI
+    # the same with the collectives' BYTES charged as well (a fixed latency makes a search tick's blocks as cheap as an ordinary tick's
+    # 54 KB): (world - 1) blocks received at 300 GB/s, a ring all-gather's bus bandwidth over xGMI.  Round 5's halo exchange of a search
+    # is what this figure shows: 41.1-41.3 us with every record gathered (6 MB per rank), 38.2 with halos (~1 MB)
     os.environ["MRS_STANDIN_GBPS"] = "300"
     try:
         wire = sharded_rank_cost(latency_us=10.0, ticks=400)
     finally:
         os.environ.pop("MRS_STANDIN_GBPS", None)
-    keep = ("split_ticks", "boundary_blocks", "blocks", "export_set", "searches", "replayed_noop_ticks")
+    keep = ("split_ticks", "boundary_blocks", "blocks", "export_set", "searches", "replayed_noop_ticks", "halo_searches", "halo_repeats", "bytes_per_tick", "bytes_per_search_tick")
     return {"workload": "rank 4 of 8 x 125000 UAVs of BASELINE configs[4] alone on the GPU, fixed-latency stand-in collective: NOT a multi-GPU measurement",
             "unit": "us per tick (wall clock, 400 ticks incl. searches)",
             "split_10us": runs[0]["us_per_tick"], "split_20us": runs[1]["us_per_tick"], "serial_10us": runs[2]["us_per_tick"],
@@ -795,6 +799,7 @@ def config5_leg(args, R):
            "collective_bytes_per_rank_per_tick": info["bytes_per_tick"], "collective_bytes_per_rank_per_search_tick": info["bytes_per_rebuild"],
            "export_set_of_rank0": info["export_count"], "export_capacity": info["export_capacity"], "uavs_per_rank": n,
            "sharded_ticks": info["ticks"], "search_ticks": info["searches"], "replayed_noop_ticks": info["noop_ticks"]}
+    _, out["halo_searches"], out["halo_repeats"], _ = sw.search_stats()  # searches that exchanged halos instead of all records / had to be repeated on all
     if R.use_dist:
         dist.barrier()  # (peer windows: nobody unmaps a window a peer may still write into)
     sw.comm_destroy()
