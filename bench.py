@@ -644,7 +644,7 @@ def sharded_rank_record(args):
     runs = [sharded_rank_cost(latency_us=10.0, ticks=400), sharded_rank_cost(latency_us=20.0, ticks=400), sharded_rank_cost(latency_us=10.0, ticks=400, split=False)]
     # the same with the collectives' BYTES charged as well (a fixed latency makes a search tick's blocks as cheap as an ordinary tick's
     # 54 KB): (world - 1) blocks received at 300 GB/s, a ring all-gather's bus bandwidth over xGMI.  Round 5's halo exchange of a search
-    # is what this figure shows: 41.1-41.3 us with every record gathered (6 MB per rank), 38.2 with halos (~1 MB)
+    # is what this figure shows: 41.6 us with every record gathered (6 MB per rank), 39.1 with halos (~1 MB) — medians of five runs
     os.environ["MRS_STANDIN_GBPS"] = "300"
     try:
         wire = sharded_rank_cost(latency_us=10.0, ticks=400)

@@ -455,21 +455,28 @@ __global__ void __launch_bounds__(256) k_own_bbox_part(const PosRecord* rec, lon
     part[blockIdx.x * 6 + 3 + threadIdx.x] = hi[threadIdx.x][0];
   }
 }
-// stage 2: the box, widened by `margin`
-__global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, double margin, double* bb, uint32_t* ctl, int cur, int force) {
+// stage 2: the box, widened by `margin`; box_out (sharded swarms): the tail of this rank's slot-map block, where the box travels to
+// the other ranks — what they choose the halo of the NEXT search by (mrs_collide_halo_*)
+__global__ void __launch_bounds__(256) k_own_bbox_final(const double* part, int nparts, double margin, double* bb, uint32_t* ctl, int cur, int force,
+                                                        double* box_out) {
   __shared__ double lo[3][256], hi[3][256];
   if (force && threadIdx.x == 0) ctl[cur ^ 1] = 0u;  // (a decided search: the flag word this tick's query may raise starts from 0 — k_skin_gathered's other job)
   if (!force && ctl[cur] == 0u) return;
   double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
-  if (threadIdx.x < BBOX_BLOCKS)
+  for (int p = threadIdx.x; p < nparts; p += 256)
     for (int c = 0; c < 3; c++) {
-      l[c] = part[threadIdx.x * 6 + c];
-      h[c] = part[threadIdx.x * 6 + 3 + c];
+      l[c] = fmin(l[c], part[p * 6 + c]);
+      h[c] = fmax(h[c], part[p * 6 + 3 + c]);
     }
   bbox_reduce_block(l, h, lo, hi);
   if (threadIdx.x < 3) {
-    bb[threadIdx.x]     = lo[threadIdx.x][0] - margin;
-    bb[3 + threadIdx.x] = hi[threadIdx.x][0] + margin;
+    const double a = lo[threadIdx.x][0] - margin, b = hi[threadIdx.x][0] + margin;  // (no usable own record: -+1e300 +- the widening — nothing is inside)
+    bb[threadIdx.x]     = a;
+    bb[3 + threadIdx.x] = b;
+    if (box_out) {
+      box_out[threadIdx.x]     = a;
+      box_out[3 + threadIdx.x] = b;
+    }
   }
 }
 
@@ -1089,6 +1096,9 @@ struct CollideWork {
   long long  h_cap = 0, h_alloc = 0;  // entries per block in use; entries allocated (all blocks together, headers included)
   int        h_world = 0;
   uint32_t*  h_ctl = nullptr;    // [0] entries appended, [1] flags (MRS_HALO_*)
+  double*    g_box_out = nullptr;  // where a search of the export-set exchange also leaves its box (mrs_collide_set_box_out)
+  double*    h_part = nullptr;     // partial boxes of k_halo_select, one per block
+  long long  h_part_cap = 0;
   bool       g_export_form = false;  // the last gathered search was one of the export-set exchange: lists end up in slot form, and of
                                      // the record copy only this rank's own range (the skin references) is kept
   // fused step + collision evaluation (step_device.inc *_coll): double-buffered positions, control words, pinned host mirror
@@ -1118,7 +1128,8 @@ static void free_work(CollideWork* w) {
   (void)hipFree(w->rec_build); (void)hipFree(w->nbr); (void)hipFree(w->nbr_cnt); (void)hipFree(w->ctl); (void)hipFree(w->g_rec_build);
   (void)hipFree(w->g_bbox);
   w->g_bbox = nullptr;
-  (void)hipFree(w->h_send); (void)hipFree(w->h_ctl);  // (h_recv lives in h_send's allocation)
+  (void)hipFree(w->h_send); (void)hipFree(w->h_ctl); (void)hipFree(w->h_part);  // (h_recv lives in h_send's allocation)
+  w->h_part = nullptr; w->h_part_cap = 0;
   w->h_send = w->h_recv = nullptr; w->h_ctl = nullptr; w->h_cap = w->h_alloc = 0;
   (void)hipFree(w->exp_slot); (void)hipFree(w->x_send);  // (x_recv and x_const live in x_send's allocation)
   w->exp_slot = nullptr; w->x_send = w->x_recv = nullptr; w->x_const = nullptr;
@@ -1369,7 +1380,8 @@ extern "C" hipError_t mrs_collide_run_lists_gathered(SwarmDev sw, CollideWork** 
   }
   // (also on list ticks: the device may decide on a search)
   hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, rec, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, force);
-  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, force);
+  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, BBOX_BLOCKS, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, force,
+                     export_form ? w->g_box_out : nullptr);
   hipLaunchKernelGGL(k_insert_gathered_lists, dim3(gN), dim3(256), 0, st, sw, rec, w->g_rec_build, n_total, my_offset, mask, head, w->next, w->ctl,
                      w->fcur, force, tid, other, T, w->nbr, w->nbr_cnt, crash, rebounce, w->g_bbox, export_form ? 1 : 0, ib);
   launch_query2<2>(query_lpu(sw.n), sw, rec, n_total, my_offset, mask, ib, head, w->next, crash, rebounce, w->ctl, w->fcur, force, w->nbr, w->nbr_cnt,
@@ -1398,44 +1410,71 @@ namespace {
 __device__ __forceinline__ const double* halo_box(const uint32_t* maps, long long stride, int boxw, int q) {
   return reinterpret_cast<const double*>(maps + (size_t)q * (size_t)stride + (size_t)boxw);
 }
-// own records -> own part of the table; the ones some other rank may list -> the send block
-__global__ void __launch_bounds__(256) k_halo_select(const PosRecord* own, int n, PosRecord* table_own, const uint32_t* maps, long long stride, int boxw, int world,
-                                                     int rank, double margin, double own_margin, HaloEntry* send, unsigned hcap, uint32_t* hctl) {
+// ONE pass over the rank's own UAVs: record from the state (what k_pack_positions writes) -> own part of the table; the records some
+// other rank may list -> the send block; the hull of the block's records -> part[block] (k_own_bbox_final reduces them); and the block
+// that finishes last writes the header
+__global__ void __launch_bounds__(256) k_halo_select(SwarmDev sw, PosRecord* table_own, const uint32_t* maps, long long stride, int boxw, int world, int rank,
+                                                     double margin, double own_margin, HaloEntry* send, unsigned hcap, uint32_t* hctl, unsigned force_flags,
+                                                     double* part) {
+  __shared__ double lo[3][256], hi[3][256];
+  __shared__ bool   last;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const PosRecord r = own[i];
-  table_own[i]      = r;
-  if (!record_usable(r)) return;
-  bool wanted = false;
-  for (int q = 0; q < world; q++) {
-    const double* b  = halo_box(maps, stride, boxw, q);  // the box of q's last search: hull of its records then, widened by the list radius
-    const double  m  = q == rank ? own_margin : margin;  // (own_margin = margin - that widening: this record within `margin` of the old hull)
-    const bool    in = r.x >= b[0] - m && r.y >= b[1] - m && r.z >= b[2] - m && r.x <= b[3] + m && r.y <= b[4] + m && r.z <= b[5] + m;
-    if (q == rank) {
-      if (!in) atomicOr(&hctl[1], MRS_HALO_MOVED);  // (also when this rank had no usable record then: NaN bounds compare false)
-    } else if (in) {
-      wanted = true;
+  double    l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+  if (i < sw.n) {
+    const TypeParams& P = sw.T[sw.F[i] >> FLAG_TYPE_SHIFT];
+    PosRecord         r;
+    r.x = sw.S[(size_t)(F_X + 0) * sw.npad + i];
+    r.y = sw.S[(size_t)(F_X + 1) * sw.npad + i];
+    r.z = sw.S[(size_t)(F_X + 2) * sw.npad + i];
+    r.mass        = P.mass;
+    r.arm_length  = P.arm_length;
+    r.prop_radius = P.prop_radius;
+    table_own[i]  = r;
+    if (record_usable(r)) {
+      l[0] = h[0] = r.x; l[1] = h[1] = r.y; l[2] = h[2] = r.z;
+      bool wanted = false;
+      for (int q = 0; q < world; q++) {
+        const double* b  = halo_box(maps, stride, boxw, q);  // the box of q's last search: hull of its records then, widened by the list radius
+        const double  m  = q == rank ? own_margin : margin;  // (own_margin = margin - that widening: this record within `margin` of the old hull)
+        const bool    in = r.x >= b[0] - m && r.y >= b[1] - m && r.z >= b[2] - m && r.x <= b[3] + m && r.y <= b[4] + m && r.z <= b[5] + m;
+        if (q == rank) {
+          if (!in) atomicOr(&hctl[1], MRS_HALO_MOVED);  // (also when this rank had no usable record then: nothing is inside its box)
+        } else if (in) {
+          wanted = true;
+        }
+      }
+      if (wanted) {
+        const uint32_t k = atomicAdd(&hctl[0], 1u);
+        if (k >= hcap) {
+          atomicOr(&hctl[1], MRS_HALO_OVERFLOW);
+        } else {
+          HaloEntry e;
+          e.x = r.x; e.y = r.y; e.z = r.z; e.mass = r.mass; e.arm_length = r.arm_length; e.prop_radius = r.prop_radius;
+          e.j = (unsigned long long)i;
+          e.pad = 0ull;
+          send[1u + k] = e;
+        }
+      }
     }
   }
-  if (!wanted) return;
-  const uint32_t k = atomicAdd(&hctl[0], 1u);
-  if (k >= hcap) {
-    atomicOr(&hctl[1], MRS_HALO_OVERFLOW);
-    return;
+  bbox_reduce_block(l, h, lo, hi);
+  if (threadIdx.x < 3) {
+    part[blockIdx.x * 6 + threadIdx.x]     = lo[threadIdx.x][0];
+    part[blockIdx.x * 6 + 3 + threadIdx.x] = hi[threadIdx.x][0];
   }
-  HaloEntry e;
-  e.x = r.x; e.y = r.y; e.z = r.z; e.mass = r.mass; e.arm_length = r.arm_length; e.prop_radius = r.prop_radius;
-  e.j = (unsigned long long)i;
-  e.pad = 0ull;
-  send[1u + k] = e;
-}
-__global__ void k_halo_header(HaloEntry* send, uint32_t* hctl, unsigned force_flags) {
-  HaloEntry h;
-  h.x = h.y = h.z = h.mass = h.arm_length = h.prop_radius = 0.0;
-  h.j   = hctl[0];  // (the number WANTED: more than the block holds with MRS_HALO_OVERFLOW — the capacity the repeat needs)
-  h.pad = hctl[1] | force_flags;
-  send[0] = h;
-  hctl[0] = hctl[1] = 0u;  // (ready for the next search)
+  __threadfence();  // this block's entries, counts and flags before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&hctl[2], 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    HaloEntry hd;
+    hd.x = hd.y = hd.z = hd.mass = hd.arm_length = hd.prop_radius = 0.0;
+    hd.j   = atomicAdd(&hctl[0], 0u);  // (the number WANTED: more than the block holds with MRS_HALO_OVERFLOW — the capacity the repeat needs)
+    hd.pad = atomicOr(&hctl[1], 0u) | force_flags;
+    send[0] = hd;
+    hctl[0] = hctl[1] = hctl[2] = 0u;  // (ready for the next search)
+  }
 }
 // own records and the received entries into the hash (the insert of k_insert_gathered_lists without the scan of n_total records)
 __global__ void __launch_bounds__(256) k_halo_insert(SwarmDev sw, PosRecord* table, PosRecord* rec_build, const HaloEntry* recv, int world, int rank, unsigned hcap,
@@ -1474,11 +1513,6 @@ __global__ void __launch_bounds__(256) k_halo_insert(SwarmDev sw, PosRecord* tab
   c.ok = c.ok && r.x >= bb[0] && r.y >= bb[1] && r.z >= bb[2] && r.x <= bb[3] && r.y <= bb[4] && r.z <= bb[5];
   insert_uav2(g, c, qc, mask, ib, head, next);
 }
-// this rank's widened box of THIS search at the tail of its slot-map block: what the next search's selection on the other ranks uses
-__global__ void k_halo_box_out(uint32_t* map, int boxw, const double* bb) {
-  double* o = reinterpret_cast<double*>(map + boxw);
-  if (threadIdx.x < 6) o[threadIdx.x] = bb[threadIdx.x];  // (no usable own record: +-1e300 +- the widening — nothing is inside, as it should be)
-}
 }  // namespace
 
 extern "C" hipError_t mrs_collide_halo_prepare(CollideWork** work, int world, long long cap, hipStream_t st) {
@@ -1512,15 +1546,27 @@ extern "C" void*     mrs_collide_halo_recv(const CollideWork* w) { return w ? (v
 // own records (packed into `own`) -> the table's own part + the send block; `maps` = every rank's slot-map block of the LAST search
 // (its tail holds that rank's widened box), `margin` = how far a UAV may be from where it was then
 // not_ready: this rank cannot search on a halo (its tables are not the ones a full search of the export-set exchange left) — its header says so
-extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, const PosRecord* own, PosRecord* table, long long n_max, int rank, int world,
-                                              const uint32_t* maps, long long stride, int boxw, int not_ready, hipStream_t st) {
+extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, PosRecord* table, long long n_max, int rank, int world, const uint32_t* maps,
+                                              long long stride, int boxw, int not_ready, hipStream_t st) {
   if (!w || !w->h_send) return hipErrorInvalidValue;
-  const double margin = SKIN2, widening = SQRT3_UP + SKIN2 + 1e-6;  // (the widening of k_own_bbox_final)
-  if (sw.n > 0)
-    hipLaunchKernelGGL(k_halo_select, dim3((unsigned)((sw.n + 255) / 256)), dim3(256), 0, st, own, sw.n, table + (size_t)rank * (size_t)n_max, maps, stride, boxw, world,
-                       rank, margin, margin - widening - 1e-9, w->h_send, (unsigned)w->h_cap, w->h_ctl);
-  hipLaunchKernelGGL(k_halo_header, dim3(1), dim3(1), 0, st, w->h_send, w->h_ctl, not_ready ? MRS_HALO_MOVED : 0u);
+  const double    margin = SKIN2, widening = SQRT3_UP + SKIN2 + 1e-6;  // (the widening of k_own_bbox_final)
+  const long long blocks = sw.n > 0 ? (sw.n + 255) / 256 : 1;
+  if (blocks > w->h_part_cap) {
+    CK(hipStreamSynchronize(st));
+    (void)hipFree(w->h_part);
+    w->h_part = nullptr;
+    w->h_part_cap = 0;
+    CK(hipMalloc(&w->h_part, sizeof(double) * 6 * (size_t)blocks));
+    w->h_part_cap = blocks;
+  }
+  hipLaunchKernelGGL(k_halo_select, dim3((unsigned)blocks), dim3(256), 0, st, sw, table + (size_t)rank * (size_t)n_max, maps, stride, boxw, world, rank, margin,
+                     margin - widening - 1e-9, w->h_send, (unsigned)w->h_cap, w->h_ctl, not_ready ? MRS_HALO_MOVED : 0u, w->h_part);
   return hipGetLastError();
+}
+// where the searches of the export-set exchange leave their box for the other ranks (the tail of this rank's slot-map block; null: nowhere)
+extern "C" void mrs_collide_set_box_out(CollideWork** work, double* box_out) {
+  if (!*work) *work = new CollideWork();
+  (*work)->g_box_out = box_out;
 }
 extern "C" int mrs_collide_halo_ready(const CollideWork* w, long long n_total) {
   return w && w->nbr && w->g_rec_build && n_total <= w->g_cap && w->g_lists_live && w->g_export_form && w->g_bbox ? 1 : 0;
@@ -1539,8 +1585,8 @@ extern "C" hipError_t mrs_collide_run_lists_halo(SwarmDev sw, CollideWork** work
   w->cur ^= 1;
   const int       ib = index_bits(n_total);
   const long long my_offset = (long long)rank * n_max;
-  hipLaunchKernelGGL(k_own_bbox_part, dim3(BBOX_BLOCKS), dim3(256), 0, st, table, my_offset, sw.n, w->g_bbox + 6, w->ctl, w->fcur, 1);
-  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->g_bbox + 6, SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, 1);
+  hipLaunchKernelGGL(k_own_bbox_final, dim3(1), dim3(256), 0, st, w->h_part, (int)((sw.n + 255) / 256), SQRT3_UP + SKIN2 + 1e-6, w->g_bbox, w->ctl, w->fcur, 1,
+                     w->g_box_out);  // (the partial boxes: k_halo_select)
   const long long threads = (long long)sw.n + (long long)world * w->h_cap;
   hipLaunchKernelGGL(k_halo_insert, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, sw, table, w->g_rec_build, w->h_recv, world, rank, (unsigned)w->h_cap, n_max,
                      mask, w->head[tid], w->next, w->ctl, tid, w->head[tid ^ 1], T, w->g_bbox, ib);
@@ -1549,15 +1595,6 @@ extern "C" hipError_t mrs_collide_run_lists_halo(SwarmDev sw, CollideWork** work
   w->fcur ^= 1;
   return hipGetLastError();
 }
-// this rank's box of the search just done -> tail of its slot-map block (after mrs_collide_export_mark, which wipes the block)
-extern "C" hipError_t mrs_collide_halo_box_out(CollideWork* w, uint32_t* map_send, int boxw, hipStream_t st) {
-  if (!w || !w->g_bbox) return hipSuccess;  // (never searched: the tail keeps the NaN words of the map's reset)
-  hipLaunchKernelGGL(k_halo_box_out, dim3(1), dim3(64), 0, st, map_send, boxw, w->g_bbox);
-  return hipGetLastError();
-}
-
-// ---- fused step + collision evaluation: what the *_coll step kernels need (single-GPU lists) ----
-// Fills `cd` for the launch with tick index `tau`; the caller launches the kernel and then calls mrs_collide_fused_advance.
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd) {
   if (!w || !w->lists_live || !w->fctl || !w->P[0]) return hipErrorInvalidValue;
   memset(cd, 0, sizeof *cd);

@@ -86,11 +86,11 @@ extern "C" long long  mrs_collide_halo_capacity(const CollideWork* w);
 extern "C" void*      mrs_collide_halo_send(const CollideWork* w);
 extern "C" void*      mrs_collide_halo_recv(const CollideWork* w);
 extern "C" int        mrs_collide_halo_ready(const CollideWork* w, long long n_total);
-extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, const PosRecord* own, PosRecord* table, long long n_max, int rank, int world,
-                                              const uint32_t* maps, long long stride, int boxw, int not_ready, hipStream_t st);
+extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, PosRecord* table, long long n_max, int rank, int world, const uint32_t* maps,
+                                              long long stride, int boxw, int not_ready, hipStream_t st);
+extern "C" void       mrs_collide_set_box_out(CollideWork** work, double* box_out);
 extern "C" hipError_t mrs_collide_run_lists_halo(SwarmDev sw, CollideWork** work, PosRecord* table, long long n_total, long long n_max, int rank, int world,
                                                  int crash, double rebounce, hipStream_t st);
-extern "C" hipError_t mrs_collide_halo_box_out(CollideWork* w, uint32_t* map_send, int boxw, hipStream_t st);
 extern "C" hipError_t mrs_collide_fused_dev(const SwarmDev* sw, CollideWork* w, unsigned tau, int eval, int crash, double rebounce, CollDev* cd);
 extern "C" void mrs_collide_fused_advance(CollideWork* w);
 extern "C" const volatile unsigned* mrs_collide_host_words(const CollideWork* w);

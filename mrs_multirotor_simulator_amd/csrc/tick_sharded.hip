@@ -49,6 +49,8 @@ int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   HIPCHK(hipMalloc(&s->x_map_recv, sizeof(uint32_t) * (size_t)map_stride(s) * (size_t)world));
   HIPCHK(hipMemsetAsync(s->x_map_recv, 0, sizeof(uint32_t) * (size_t)map_stride(s) * (size_t)world, s->stream));  // (the stand-in collective leaves absent ranks' maps alone)
   HIPCHK(hipMemsetAsync(s->comm_send, 0xFF, sizeof(PosRecord) * (size_t)s->comm_n_max, s->stream));  // NaN padding records never collide
+  HIPCHK(hipMemsetAsync(s->x_map_send, 0xFF, sizeof(uint32_t) * (size_t)map_stride(s), s->stream));      // (the box at its tail: NaN bounds until a search writes it — for good on a rank without UAVs)
+  mrs_collide_set_box_out(&s->cwork, reinterpret_cast<double*>(s->x_map_send + map_boxw(s)));
   return MRS_OK;
 }
 }  // namespace mrs_host
@@ -117,6 +119,7 @@ int mrs_swarm_comm_destroy(mrs_swarm_t* s) {
   mrs_collide_invalidate_gathered(s->cwork);
   if (s->comm_send) (void)hipFree(s->comm_send);
   if (s->comm_recv) (void)hipFree(s->comm_recv);
+  if (s->cwork) mrs_collide_set_box_out(&s->cwork, nullptr);
   if (s->x_map_send) (void)hipFree(s->x_map_send);
   if (s->x_map_recv) (void)hipFree(s->x_map_recv);
   s->comm_send = s->comm_recv = nullptr;
@@ -246,7 +249,6 @@ int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, 
   s->x_ok = false;
   s->x_searches++;
   s->halo_pass = allow_halo && halo_next(s);
-  if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
   s->fext_active = true;
   s->nbr_dirty   = true;  // (a later single-GPU tick starts from a search of its own)
   if (s->halo_pass) {
@@ -254,19 +256,21 @@ int export_search_enqueue(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, 
     HIPCHK(mrs_collide_halo_prepare(&s->cwork, world, s->halo_cap, s->stream));
     // (a rank whose tables are not what a search of this exchange left — ticks of another kind in between, on this rank only — says so in its header)
     const int ready = s->n == 0 || mrs_collide_halo_ready(s->cwork, n_rec);
-    HIPCHK(mrs_collide_halo_select(s->view(), s->cwork, s->comm_send, s->comm_recv, n_max, rank, world, s->x_map_recv, stride, (int)map_boxw(s), ready ? 0 : 1, s->stream));
+    // (one pass over the own UAVs: records into the table, halo entries, partial boxes, header)
+    HIPCHK(mrs_collide_halo_select(s->view(), s->cwork, s->comm_recv, n_max, rank, world, s->x_map_recv, stride, (int)map_boxw(s), ready ? 0 : 1, s->stream));
     if ((rc = comm_allgather(s, mrs_collide_halo_send(s->cwork), mrs_collide_halo_recv(s->cwork), sizeof(HaloEntry) * (size_t)(s->halo_cap + 1)))) return rc;
     if (s->n > 0 && ready) HIPCHK(mrs_collide_run_lists_halo(s->view(), &s->cwork, s->comm_recv, n_rec, n_max, rank, world, c.crash, c.rebounce, s->stream));
   } else {
+    if (s->n > 0) HIPCHK(mrs_launch_pack_positions(s->view(), s->comm_send, s->stream));
     if ((rc = comm_allgather(s, s->comm_send, s->comm_recv, sizeof(PosRecord) * (size_t)n_max))) return rc;
     if (s->n > 0)
       HIPCHK(mrs_collide_run_lists_gathered(s->view(), &s->cwork, s->comm_recv, n_rec, (int64_t)rank * n_max, c.crash, c.rebounce, /*force=*/1, s->stream));
   }
   const long long cap = mrs_collide_export_capacity(s->cwork);
   HIPCHK(mrs_collide_export_prepare(s->view(), &s->cwork, world, cap > 0 ? cap : 64, /*zero=*/0, s->stream));  // (zeroed by the marking launches)
-  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, stride, rank, s->x_map_send, s->shard_split ? (double)MRS_PRED_HORIZON * dt : -1.0, c.rebounce,
+  // (the map's reset stops short of its tail: the search has left this rank's box there — what the next search's halos are chosen by)
+  HIPCHK(mrs_collide_export_mark(s->view(), s->cwork, n_max, map_boxw(s), rank, s->x_map_send, s->shard_split ? (double)MRS_PRED_HORIZON * dt : -1.0, c.rebounce,
                                  s->stream));
-  HIPCHK(mrs_collide_halo_box_out(s->cwork, s->x_map_send, (int)map_boxw(s), s->stream));  // this search's box: what the next one's halo is chosen by
   if ((rc = comm_allgather(s, s->x_map_send, s->x_map_recv, sizeof(uint32_t) * (size_t)stride))) return rc;
   // the heads of all ranks' maps: export count, lanes over the list capacity so far — the same numbers on every rank
   const uint32_t* heads = nullptr;  // (pinned host words, written by one small launch; valid once the stream has been synchronised)
