@@ -260,8 +260,10 @@ int mrs_swarm_handle_collisions_gathered(mrs_swarm_t* s, const void* dev_records
 /* The same exchange done by the library itself, for hosts that do not want to drive the collective: it is issued on the swarm's own
  * stream between the kernels, so a whole run of ticks is one call.  Two exchanges exist (mrs_swarm_set_exchange):
  *   MRS_EXCHANGE_EXPORT_SETS (default) — SURVEY 8e v2, "all-gather of boundary-UAV positions": a tick that repeats the neighbour
- *       search gathers all 48-B records; every tick until the next search gathers only the UAVs some other rank lists (32 B each,
- *       padded to the largest export set), and the collision tick is evaluated by the next step kernel (as on one GPU);
+ *       search gathers the records another rank can list (those inside its bounding box of the last search; 64 B each — the first
+ *       search, and any search whose halo turns out too small, gathers all 48-B records: mrs_swarm_get_search_stats); every tick until
+ *       the next search gathers only the UAVs some other rank lists (32 B each, padded to the largest export set), and the collision
+ *       tick is evaluated by the next step kernel (as on one GPU);
  *   MRS_EXCHANGE_FULL_GATHER — all 48-B records on every tick.
  * Results are identical.  Shards are equal-count index ranges of the caller's (spatially sorted, see mrs_slab_partition) order.
  * Collective backends:
