@@ -87,8 +87,10 @@ NOTES = {
                    "collisions + ground) as mrs_swarm_tick_n runs it, and (spawned_in_cell_order) the same swarm spawned in the order mrs_cell_order suggests; literal: the bit-faithful flavour on the headline workload; config2: "
                    "BASELINE configs[1] (400 f550 on the tmux grid); io_tick: config 3 with the publisher payload of every UAV downloaded and a "
                    "command block uploaded every tick (SURVEY 8f rank 2), serial and pipelined; sharded_rank_standin: one rank of 8 x 125 000 "
-                   "alone on the GPU behind a fixed-latency stand-in collective (NOT a multi-GPU measurement); config5: BASELINE configs[4] "
-                   "through mrs_swarm_tick_sharded_n on the ranks of this run",
+                   "alone on the GPU behind a fixed-latency stand-in collective (NOT a multi-GPU measurement; split_10us_plus_bytes_at_300GBps: the "
+                   "stand-in also charges every collective its bytes, (world - 1) blocks at 300 GB/s; halo_searches / halo_repeats: searches "
+                   "that exchanged the records inside another rank's box instead of all records / had to be repeated on all of them); "
+                   "config5: BASELINE configs[4] through mrs_swarm_tick_sharded_n on the ranks of this run",
     "rehearsal": "MRS_BENCH_REHEARSAL=1: the --gpus N code path (torch.distributed.run child, one process per rank, process group, MAX over "
                  "ranks, config-5 leg, guarded peer-window child run) with every rank on cuda:0 and a gloo process group; the config-5 exchange "
                  "is a host all-gather over gloo or the peer windows over IPC.  Exercises the code, measures nothing: n_devices says 1",
