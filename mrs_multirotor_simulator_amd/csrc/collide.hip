@@ -1411,13 +1411,12 @@ __device__ __forceinline__ const double* halo_box(const uint32_t* maps, long lon
   return reinterpret_cast<const double*>(maps + (size_t)q * (size_t)stride + (size_t)boxw);
 }
 // ONE pass over the rank's own UAVs: record from the state (what k_pack_positions writes) -> own part of the table; the records some
-// other rank may list -> the send block; the hull of the block's records -> part[block] (k_own_bbox_final reduces them); and the block
-// that finishes last writes the header
+// other rank may list -> the send block; the hull of the block's records -> part[block] (k_own_bbox_final reduces them).
+// (The header is a launch of its own, k_halo_header: written by "the block that finishes last" it needed a device-scope release in
+//  every wave — an L2 write-back each on this chip — and the kernel took 44.6 us instead of 8.)
 __global__ void __launch_bounds__(256) k_halo_select(SwarmDev sw, PosRecord* table_own, const uint32_t* maps, long long stride, int boxw, int world, int rank,
-                                                     double margin, double own_margin, HaloEntry* send, unsigned hcap, uint32_t* hctl, unsigned force_flags,
-                                                     double* part) {
+                                                     double margin, double own_margin, HaloEntry* send, unsigned hcap, uint32_t* hctl, double* part) {
   __shared__ double lo[3][256], hi[3][256];
-  __shared__ bool   last;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double    l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
   if (i < sw.n) {
@@ -1462,19 +1461,14 @@ __global__ void __launch_bounds__(256) k_halo_select(SwarmDev sw, PosRecord* tab
     part[blockIdx.x * 6 + threadIdx.x]     = lo[threadIdx.x][0];
     part[blockIdx.x * 6 + 3 + threadIdx.x] = hi[threadIdx.x][0];
   }
-  __threadfence();  // this block's entries, counts and flags before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&hctl[2], 1u) == gridDim.x - 1u;
-  __syncthreads();
-  if (last && threadIdx.x == 0) {
-    __threadfence();
-    HaloEntry hd;
-    hd.x = hd.y = hd.z = hd.mass = hd.arm_length = hd.prop_radius = 0.0;
-    hd.j   = atomicAdd(&hctl[0], 0u);  // (the number WANTED: more than the block holds with MRS_HALO_OVERFLOW — the capacity the repeat needs)
-    hd.pad = atomicOr(&hctl[1], 0u) | force_flags;
-    send[0] = hd;
-    hctl[0] = hctl[1] = hctl[2] = 0u;  // (ready for the next search)
-  }
+}
+__global__ void k_halo_header(HaloEntry* send, uint32_t* hctl, unsigned force_flags) {
+  HaloEntry hd;
+  hd.x = hd.y = hd.z = hd.mass = hd.arm_length = hd.prop_radius = 0.0;
+  hd.j   = hctl[0];  // (the number WANTED: more than the block holds with MRS_HALO_OVERFLOW — the capacity the repeat needs)
+  hd.pad = hctl[1] | force_flags;
+  send[0] = hd;
+  hctl[0] = hctl[1] = 0u;  // (ready for the next search)
 }
 // own records and the received entries into the hash (the insert of k_insert_gathered_lists without the scan of n_total records)
 __global__ void __launch_bounds__(256) k_halo_insert(SwarmDev sw, PosRecord* table, PosRecord* rec_build, const HaloEntry* recv, int world, int rank, unsigned hcap,
@@ -1560,7 +1554,8 @@ extern "C" hipError_t mrs_collide_halo_select(SwarmDev sw, CollideWork* w, PosRe
     w->h_part_cap = blocks;
   }
   hipLaunchKernelGGL(k_halo_select, dim3((unsigned)blocks), dim3(256), 0, st, sw, table + (size_t)rank * (size_t)n_max, maps, stride, boxw, world, rank, margin,
-                     margin - widening - 1e-9, w->h_send, (unsigned)w->h_cap, w->h_ctl, not_ready ? MRS_HALO_MOVED : 0u, w->h_part);
+                     margin - widening - 1e-9, w->h_send, (unsigned)w->h_cap, w->h_ctl, w->h_part);
+  hipLaunchKernelGGL(k_halo_header, dim3(1), dim3(1), 0, st, w->h_send, w->h_ctl, not_ready ? MRS_HALO_MOVED : 0u);
   return hipGetLastError();
 }
 // where the searches of the export-set exchange leave their box for the other ranks (the tail of this rank's slot-map block; null: nowhere)
