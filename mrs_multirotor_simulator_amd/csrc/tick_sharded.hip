@@ -331,10 +331,9 @@ int export_search_finish(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, i
   // (the lists are in export form now; collide.hip remembers that, and the full exchange would start with a search of its own)
   s->x_ok = true;
   s->halo_ok = true;  // (every rank's box of this search sits in x_map_recv)
-  if (s->halo_cap < 1) {  // first guess, an eighth of a shard; the first halo search reports what is needed
-    s->halo_cap = ((n_max / 8 + 64 + 63) / 64) * 64;
-    if (s->halo_cap > halo_cap_max(s)) s->halo_cap = halo_cap_max(s);
-  }
+  // the first halo search sends blocks as large as a full gather's (no more bytes than the search it replaces, and no overflow short
+  // of "most records wanted", which is the back-off's case); it reports what is needed and the capacity follows
+  if (s->halo_cap < 1) s->halo_cap = halo_cap_max(s);
   if (s->halo_backoff > 0) s->halo_backoff--;
   s->tau  = 0;
   return MRS_OK;
