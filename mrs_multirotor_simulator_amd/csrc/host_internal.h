@@ -211,7 +211,7 @@ struct mrs_swarm {
   // halo exchange of a search (collide.hip mrs_collide_halo_*; MRS_SEARCH_HALO=0: every search gathers all records, as up to round 4)
   bool      halo_trace = false;  // MRS_HALO_TRACE=1: one line on stderr per halo search
   bool      halo_enabled = true, halo_ok = false, halo_pass = false;  // ok: the last search left every rank's box in the maps; pass: the queued search is a halo one
-  int64_t   halo_cap = 0, halo_backoff = 0;                                            // entries per block of the next halo search — the same on every rank
+  int64_t   halo_cap = 0, halo_backoff = 0, halo_backoff_len = 16;                                            // entries per block of the next halo search — the same on every rank
   int64_t   x_halo_searches = 0, x_halo_repeats = 0;
   bool      early_search = true;    // tuning: MRS_EARLY_SEARCH=0 — a certain search waits for the segment's synchronisation (round 3)
   bool      shard_split = true;     // tuning: MRS_SHARD_SPLIT=0 keeps every tick in the serial form (fused launch, then the collective)

@@ -39,6 +39,7 @@ int comm_buffers(mrs_swarm* s, int world, int rank, int64_t n_total) {
   s->halo_ok      = false;
   s->halo_cap     = 0;
   s->halo_backoff = 0;
+  s->halo_backoff_len = 16;
   if (const char* e = getenv("MRS_SEARCH_HALO")) s->halo_enabled = atoi(e) != 0;
   s->halo_trace = getenv("MRS_HALO_TRACE") && atoi(getenv("MRS_HALO_TRACE")) != 0;
   s->x_last_overflow.assign((size_t)world, 0u);
@@ -294,7 +295,12 @@ int export_search_finish(mrs_swarm* s, const mrs_swarm::Collide& c, double dt, i
     const int64_t cap_max = halo_cap_max(s);
     int64_t       next    = (((int64_t)wanted + (int64_t)wanted / 4 + 64 + 63) / 64) * 64;  // headroom: the sets drift from search to search
     if (next > cap_max) next = cap_max;
-    if ((int64_t)wanted > cap_max) s->halo_backoff = 16;  // most records would travel anyway: the next searches gather them all
+    if ((int64_t)wanted > cap_max) {  // most records would travel anyway: the next searches gather them all — 16 of them, then twice as many each time it happens again
+      s->halo_backoff     = s->halo_backoff_len;
+      s->halo_backoff_len = s->halo_backoff_len < 1024 ? 2 * s->halo_backoff_len : 1024;
+    } else if (!flags) {
+      s->halo_backoff_len = 16;
+    }
     if (s->halo_trace)
       fprintf(stderr, "[mrs halo] rank %d search %lld: most entries wanted by a rank %u, block capacity %lld (next %lld, at most %lld), flags %u%s\n", rank,
               (long long)s->x_searches, wanted, (long long)s->halo_cap, (long long)next, (long long)cap_max, flags, flags ? " -> repeated on all records" : "");
