@@ -660,6 +660,16 @@ public:
     mrs_throw_on_error(mrs_swarm_comm_info(s_, &ci));
     return ci;
   }
+  // neighbour searches of the export-set exchange on this rank: all, the ones that exchanged halos instead of all records, the halo
+  // searches repeated on all records, entries per rank of the next halo block (mrs_swarm_get_search_stats)
+  struct SearchStats {
+    int64_t searches, halo_searches, halo_repeats, halo_capacity;
+  };
+  SearchStats searchStats() {
+    SearchStats st{};
+    mrs_throw_on_error(mrs_swarm_get_search_stats(s_, &st.searches, &st.halo_searches, &st.halo_repeats, &st.halo_capacity));
+    return st;
+  }
   // spatially coherent shards for a swarm addressed by public index: order[k] = public index at position k of the x-sorted order;
   // rank r of `world` holds order[lo_r, hi_r) with equal-count ranges (the first n % world ranks one more)
   static std::vector<int64_t> slabPartition(const std::vector<Eigen::Vector3d>& pos, int world) {

@@ -150,6 +150,10 @@ int main() {
     CHECK(worst3 < 1e-12);
     CHECK(ci.exchange == MRS_EXCHANGE_EXPORT_SETS && ci.ticks == 150 && ci.searches >= 1 && ci.searches < 60);
     CHECK(ci.bytes_per_tick < ci.bytes_per_rebuild);
+    const UavSwarm::SearchStats ss = shard[1]->searchStats();  // (the same counts on every rank: the decisions follow from collective data)
+    std::printf("searches %lld, of them on a halo exchange %lld, repeated on all records %lld\n", (long long)ss.searches, (long long)ss.halo_searches, (long long)ss.halo_repeats);
+    CHECK(ss.searches == ci.searches && ss.halo_searches + ss.halo_repeats <= ss.searches && ss.halo_repeats <= ss.halo_searches);
+    for (int r = 0; r < world; r++) CHECK(shard[(size_t)r]->searchStats().halo_searches == ss.halo_searches);
     th.clear();
     for (int r = 0; r < world; r++) th.emplace_back([&, r] { shard[(size_t)r]->commDestroy(); });
     for (auto& t : th) t.join();
