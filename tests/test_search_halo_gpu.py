@@ -128,3 +128,16 @@ def test_shards_without_spatial_order_fall_back_to_the_full_gather(mrs, oracle, 
         assert searches >= 3 and on_halo == repeats and on_halo <= 1 + searches // 16 and cap == 0, (searches, on_halo, repeats, cap)
     halo.close()
     full.close()
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_halo_searches_under_random_host_writes(mrs, oracle, seed):
+    """tests/campaigns/halo_host_writes.py, two seeds of it: UAVs moved by set_state between calls (a few metres, across the slabs, out of
+    the hull, next to a UAV of another rank), holds, new commands — every call against the oracle, every rank with the same counters"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("halo_host_writes", os.path.join(os.path.dirname(os.path.abspath(__file__)), "campaigns", "halo_host_writes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    searches, on_halo, repeats = mod.scenario(seed)[:3]
+    assert searches >= 3 and on_halo >= 1, (searches, on_halo, repeats)
