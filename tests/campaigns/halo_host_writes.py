@@ -13,8 +13,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["MRS_SHARD_SPLIT_MIN_BLOCKS"] = "1"
-os.environ["MRS_SHARD_SPLIT_MAX_FRACTION"] = "0.95"
 import helpers  # noqa: E402
 import mrs_multirotor_simulator_amd as M  # noqa: E402
 from helpers import RTOL_LITERAL  # noqa: E402
@@ -90,6 +88,8 @@ def scenario(seed, verbose=True):
 
 
 if __name__ == "__main__":
+    os.environ["MRS_SHARD_SPLIT_MIN_BLOCKS"] = "1"  # (split ticks on swarms of a few thousand UAVs: read when a swarm is created)
+    os.environ["MRS_SHARD_SPLIT_MAX_FRACTION"] = "0.95"
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     M.load_library()

@@ -131,11 +131,13 @@ def test_shards_without_spatial_order_fall_back_to_the_full_gather(mrs, oracle, 
 
 
 @pytest.mark.parametrize("seed", [3, 11])
-def test_halo_searches_under_random_host_writes(mrs, oracle, seed):
+def test_halo_searches_under_random_host_writes(mrs, oracle, monkeypatch, seed):
     """tests/campaigns/halo_host_writes.py, two seeds of it: UAVs moved by set_state between calls (a few metres, across the slabs, out of
     the hull, next to a UAV of another rank), holds, new commands — every call against the oracle, every rank with the same counters"""
     import importlib.util
     import os
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MIN_BLOCKS", "1")  # split ticks on swarms of a few thousand UAVs, as the campaign runs them
+    monkeypatch.setenv("MRS_SHARD_SPLIT_MAX_FRACTION", "0.95")
     spec = importlib.util.spec_from_file_location("halo_host_writes", os.path.join(os.path.dirname(os.path.abspath(__file__)), "campaigns", "halo_host_writes.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
