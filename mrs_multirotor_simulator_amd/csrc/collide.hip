@@ -1728,7 +1728,8 @@ __global__ void k_class_list(int n, long long n_max, int rank, const uint32_t* n
     const long long g = (long long)nbr[(size_t)k * (size_t)n + (size_t)i], q = g / n_max;
     if (q == (long long)rank && (blk_class[(g - q * n_max) >> 6] & MRS_BLK_BOUNDARY)) l1 = true;
   }
-  if (l1 && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) atomicAdd(&fctl[CTL_NL1], 1u);
+  // (the layer-1 blocks are listed from the back of the block list — the boundary blocks fill it from the front, a block is never both)
+  if (l1 && !(atomicOr(&blk_class[i >> 6], MRS_BLK_LAYER1) & MRS_BLK_LAYER1)) blk_list[(uint32_t)((n + 63) / 64) - 1u - atomicAdd(&fctl[CTL_NL1], 1u)] = (uint32_t)(i >> 6);
 }
 
 // start of a run of split ticks behind launch `tau`: every block counts as finished by that launch, nobody has arrived yet

@@ -170,9 +170,9 @@ struct CollDev {
   // split sharded ticks: block classes, the boundary launch's block list, per-block epoch words (tick index of the last launch that
   // finished the block), and the displacement bound's step-dependent factors
   const uint32_t*     blk_class;  // [blocks]
-  const uint32_t*     blk_list;   // [n_bnd]
+  const uint32_t*     blk_list;   // [blocks]: the boundary blocks from the front, the layer-1 blocks from the back
   uint32_t*           epoch;      // [blocks]
-  uint32_t            n_bnd, _pad3;
+  uint32_t            n_bnd, n_l1;  // n_l1 > 0 (interior launch): the grid is n_l1 + blocks, its first n_l1 blocks take the layer-1 blocks of the list
   double              pred_hdt;   // horizon * dt; < 0: nothing is announced (serial protocol, MRS_SHARD_SPLIT=0: every launch tests exactly)
   double              pred_lim;   // sqrt(lim2)
 };

@@ -401,7 +401,10 @@ int launch_split_export(mrs_swarm* s, double dt, const mrs_swarm::Collide& eval,
   if (rc) return rc;
   part = cd;
   mrs_collide_export_part(&part, MRS_PART_INTERIOR, s->x_nbnd, dt, bound_ok);
-  if (!(exp_skip & 4)) HIPCHK(launch(part, 0, s->stream_i ? s->stream_i : s->stream2));
+  // (tuning: MRS_INTERIOR_L1_FIRST=1 — the interior launch's first blocks are its layer-1 blocks, the ones the next boundary launch waits for)
+  static const bool l1_first = getenv("MRS_INTERIOR_L1_FIRST") && atoi(getenv("MRS_INTERIOR_L1_FIRST")) != 0;
+  part.n_l1 = l1_first ? s->x_nl1 : 0u;
+  if (!(exp_skip & 4)) HIPCHK(launch(part, part.n_l1 ? (int)(part.n_l1 + (unsigned)((s->n + 63) / 64)) : 0, s->stream_i ? s->stream_i : s->stream2));
   mrs_collide_fused_advance(s->cwork);
   s->tau++;
   s->x_split_ticks++;
